@@ -1,0 +1,232 @@
+/*
+ * kr_trace.h -- C ABI of libkrtrace.so, the MI355X (gfx950) Kerr null-geodesic hot path.
+ *
+ * The reference (wilkinsdr/raytrace_cpu) has no FFI/plugin layer: its boundary is the C++ class API
+ * Raytracer<T> / PointSource<T> / ImagePlane<T> (src/raytracer/raytracer.h:85-198).  This header is
+ * the thin C ABI that a replacement Raytracer<T> calls from inside those member functions; each entry
+ * point below names the reference function (file:line, relative to the reference tree) it replaces.
+ * The host-side mirror of the class API that does exactly that lives in raytrace_cpu_amd/host/.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all sizes are int64_t; all entry points return 0 on success and a
+ *     negative KR_E* code on failure (kr_last_error() gives the message).  There is NO CPU fallback:
+ *     without a usable HIP device every compute entry point returns KR_ENODEVICE.
+ *   - "_dev" entry points take DEVICE pointers (hipMalloc / torch data_ptr) and a hipStream_t passed
+ *     as void* (NULL = default stream); they enqueue work and return without synchronising unless a
+ *     kr_stats* is requested (stats need the kernel's counters -> the call synchronises the stream).
+ *   - entry points without "_dev" take HOST pointers, stage through private device buffers and return
+ *     with the host arrays updated (the contract of Raytracer<T>::run_raytrace: results are in
+ *     rays[] when it returns, raytracer.cpp:63-127).
+ *   - kr_ray_f64 / kr_ray_f32 are layout-identical to Ray<double> / Ray<float>
+ *     (raytracer.h:65-78; 144 B / 84 B), so `rays` can be handed over without conversion.
+ */
+#ifndef KR_TRACE_H_
+#define KR_TRACE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KR_ABI_VERSION 1
+
+/* error codes */
+#define KR_OK          0
+#define KR_EINVAL     -1   /* bad argument (NULL pointer, unknown integrator/stop kind, Euler+destination) */
+#define KR_ENODEVICE  -2   /* no HIP device / HIP runtime unusable */
+#define KR_EHIP       -3   /* a HIP call failed; see kr_last_error() */
+#define KR_ENOMEM     -4
+
+/* enum class Integrator { Euler, RK4, RK45 }  (raytracer.h:83) */
+#define KR_EULER 0
+#define KR_RK4   1
+#define KR_RK45  2
+
+/* stop surfaces: the theta-limit overloads (raytracer.cpp:129,755,1260) and the three concrete
+ * RayDestination classes (ray_destination.h:86,116,173) as POD descriptors */
+#define KR_STOP_THETA      0   /* theta_max field; stop_params unused */
+#define KR_STOP_FLATDISC   1   /* stop_params = {theta_lim} */
+#define KR_STOP_DISC_ISCO  2   /* stop_params = {r_isco, r_out, theta_lim} */
+#define KR_STOP_FLATPLANE  3   /* stop_params = {incl, phi0, z_s} */
+
+/* ray status bit flags (raytracer.h:58-63) + one extension */
+#define KR_STATUS_DEST        (1 << 0)
+#define KR_STATUS_HORIZON     (1 << 1)
+#define KR_STATUS_RLIM        (1 << 2)
+#define KR_STATUS_STEPLIM     (1 << 3)
+#define KR_STATUS_ERGO        (1 << 4)
+#define KR_STATUS_NEG_ENERGY  (1 << 5)
+/* extension: the RK45 retry loop met a NaN error norm.  The reference never leaves that loop
+ * (raytracer.cpp:1438-1541); the device path ends the ray and sets this bit instead. */
+#define KR_STATUS_NAN         (1 << 6)
+
+/* defaults, raytracer.h:19-44 */
+#define KR_PRECISION        100.0
+#define KR_THETA_PRECISION  50.0
+#define KR_MAXDT            1.0
+#define KR_MAXDT_RLIM       100.0
+#define KR_MAXDPHI          0.1
+#define KR_STEPLIM          10000000
+#define KR_RK45_STEPLIM     100000
+#define KR_MIN_STEP         1e-3
+
+typedef struct kr_ray_f64 {
+    double t, r, theta, phi;
+    double pt, pr, ptheta, pphi;
+    double k, h, Q;
+    double emit, redshift;
+    int32_t steps, status, rdot_sign, thetadot_sign, rdot_flips, equatorial_crossings;
+    double alpha, beta;
+} kr_ray_f64;
+
+typedef struct kr_ray_f32 {
+    float t, r, theta, phi;
+    float pt, pr, ptheta, pphi;
+    float k, h, Q;
+    float emit, redshift;
+    int32_t steps, status, rdot_sign, thetadot_sign, rdot_flips, equatorial_crossings;
+    float alpha, beta;
+} kr_ray_f32;
+
+/* Everything Raytracer<T>::run_raytrace reads besides rays[] (members raytracer.h:89-99 + call
+ * arguments raytracer.h:112-122).  Doubles carry float values exactly for the f32 entry points. */
+typedef struct kr_params {
+    double spin;             /* as stored by Raytracer (ImagePlane has already negated it, imageplane.cpp:12) */
+    double horizon;          /* kerr_horizon(spin) or set_boundary() value */
+    double precision;        /* PRECISION */
+    double theta_precision;  /* THETA_PRECISION */
+    double max_tstep;        /* MAXDT */
+    double maxtstep_rlim;    /* MAXDT_RLIM */
+    double max_phistep;      /* MAXDPHI */
+    double rk45_tol;         /* 1e-8 */
+    double r_max;            /* rlim */
+    double theta_max;        /* thetalim (KR_STOP_THETA only) */
+    double stop_params[4];
+    int32_t integrator;      /* KR_EULER / KR_RK4 / KR_RK45 */
+    int32_t stop_kind;       /* KR_STOP_* */
+    int32_t steplim;         /* <=0: STEPLIM for Euler/RK4, RK45_STEPLIM for RK45 (raytracer.cpp:80) */
+    int32_t flags;           /* reserved, 0 */
+} kr_params;
+
+/* counters gathered by the trace kernel (what integrator_perf_test.cpp:82-93 derives on the host) */
+typedef struct kr_stats {
+    int64_t rays_total;      /* n */
+    int64_t rays_traced;     /* rays that entered a propagate loop (steps >= 0 and < steplim on entry) */
+    int64_t steps_total;     /* sum of per-call `steps` over traced rays (every ++steps, incl. theta-flip iterations) */
+    int64_t rk45_attempts;   /* RK45: trial steps evaluated (accepted + rejected) */
+    int64_t rk45_rejects;    /* RK45: trial steps rejected */
+    double  kernel_ms;       /* trace kernel duration, HIP events on the launch stream */
+    double  h2d_ms, d2h_ms;  /* host-buffer entry points only */
+} kr_stats;
+
+/* PointSource<T> ctor arguments (pointsource.h:24, pointsource.cpp:11-64) */
+typedef struct kr_pointsource {
+    double pos[4];
+    double V, spin, tol;
+    double dcosalpha, dbeta;
+    double cosalpha0, cosalphamax, beta0, betamax;
+    double E;
+} kr_pointsource;
+
+/* ImagePlane<T> ctor arguments (imageplane.h:26, imageplane.cpp:11-121); `spin` is the PHYSICAL spin,
+ * the ctor's negation is applied inside */
+typedef struct kr_imageplane {
+    double dist, inc_deg;
+    double x0, xmax, dx;
+    double y0, ymax, dy;
+    double spin, phi0, precision;
+} kr_imageplane;
+
+/* radial histogram of src/emissivity/emissivity.cpp:96-126 */
+typedef struct kr_emis_bins {
+    double r_min;            /* first bin edge */
+    double dr;               /* logbin: ratio between edges; linear: width */
+    double r_isco;           /* rays with r < r_isco are dropped */
+    double gamma;            /* emis += redshift^-gamma */
+    double spin;             /* unused by the filter (z = r cos(theta) only) but kept for symmetry with cartesian() */
+    double num_primary_rays; /* flux += 1/(num_primary_rays * redshift) */
+    int32_t nr;
+    int32_t logbin;
+} kr_emis_bins;
+
+/* image accumulation of src/imageplane/imageplane_disc_image.cpp:122-161 */
+typedef struct kr_image_bins {
+    double x0, y0, img_dx, img_dy;
+    double r_isco, r_disc;
+    double q1, rb1, q2, rb2, q3;   /* powerlaw3, imageplane_disc_image.cpp:20-28 */
+    int32_t img_nx, img_ny;
+    int32_t flip_image;
+    int32_t pad;
+} kr_image_bins;
+
+/* ---- runtime ---------------------------------------------------------------------------------- */
+int         kr_abi_version(void);
+const char* kr_last_error(void);
+int         kr_device_count(void);                 /* <0: KR_ENODEVICE */
+int         kr_set_device(int device);
+int         kr_device_info(int* cu_count, int* clock_khz, int64_t* hbm_bytes, char* name, int name_len);
+void        kr_params_default(kr_params* p, double spin);   /* Raytracer ctor defaults, raytracer.cpp:12-22 */
+int64_t     kr_pointsource_count(const kr_pointsource* s, int32_t* n_cosalpha, int32_t* n_beta);   /* pointsource.cpp:12,16-17 */
+int64_t     kr_imageplane_count(const kr_imageplane* s, int32_t* nx, int32_t* ny);                 /* imageplane.cpp:12-14 */
+
+/* ---- the hot path: Raytracer<T>::run_raytrace, both overloads (raytracer.cpp:63-127, 972-1034) -- */
+int kr_trace_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, kr_stats* stats);
+int kr_trace_f32(const kr_params* p, kr_ray_f32* rays, int64_t n, kr_stats* stats);
+int kr_trace_dev_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, kr_stats* stats);
+int kr_trace_dev_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, kr_stats* stats);
+
+/* ---- O(N) passes either side of it ----------------------------------------------------------- */
+/* Raytracer<T>::redshift_start(V, reverse, projradius)  raytracer.cpp:342-417 */
+int kr_redshift_start_f64(double spin, double V, int reverse, int projradius, kr_ray_f64* rays, int64_t n);
+int kr_redshift_start_dev_f64(double spin, double V, int reverse, int projradius, void* d_rays, int64_t n, void* stream);
+/* Raytracer<T>::redshift(V, reverse, projradius, motion)  raytracer.cpp:420-447, 480-553 */
+int kr_redshift_f64(double spin, double V, int reverse, int projradius, int motion, kr_ray_f64* rays, int64_t n);
+int kr_redshift_dev_f64(double spin, double V, int reverse, int projradius, int motion, void* d_rays, int64_t n, void* stream);
+/* Raytracer<T>::redshift(RayDestination*, reverse, ...) with the default four_velocity()
+ * (raytracer.cpp:450-477, 556-600; ray_destination.h:59-78: every concrete class keeps velocity() = -1) */
+int kr_redshift_dest_f64(double spin, int reverse, kr_ray_f64* rays, int64_t n);
+int kr_redshift_dest_dev_f64(double spin, int reverse, void* d_rays, int64_t n, void* stream);
+/* Raytracer<T>::range_phi(min, max)  raytracer.cpp:603-622 */
+int kr_range_phi_f64(double lo, double hi, kr_ray_f64* rays, int64_t n);
+int kr_range_phi_dev_f64(double lo, double hi, void* d_rays, int64_t n, void* stream);
+/* Raytracer<T>::calculate_momentum()  raytracer.cpp:704-753 */
+int kr_calculate_momentum_f64(double spin, kr_ray_f64* rays, int64_t n);
+int kr_calculate_momentum_dev_f64(double spin, void* d_rays, int64_t n, void* stream);
+
+/* ---- ray sources: PointSource / ImagePlane ctors (pointsource.cpp:11-64, imageplane.cpp:11-121) -- */
+int kr_pointsource_init_f64(const kr_pointsource* s, kr_ray_f64* rays, int64_t n);
+int kr_pointsource_init_dev_f64(const kr_pointsource* s, void* d_rays, int64_t n, void* stream);
+int kr_imageplane_init_f64(const kr_imageplane* s, kr_ray_f64* rays, int64_t n);
+int kr_imageplane_init_dev_f64(const kr_imageplane* s, void* d_rays, int64_t n, void* stream);
+
+/* ---- reducers of the two target apps --------------------------------------------------------- */
+/* emissivity.cpp:96-126.  Outputs (length nr each): count, flux, emis, sum_redshift, sum_time -- the raw
+ * accumulators BEFORE the divisions of emissivity.cpp:128-134; *disc_count = rays passing the filter. */
+int kr_reduce_emissivity_f64(const kr_emis_bins* b, const kr_ray_f64* rays, int64_t n,
+                             int64_t* count, double* flux, double* emis, double* sum_redshift, double* sum_time,
+                             int64_t* disc_count);
+/* d_hist: device buffer of nr*5+1 doubles laid out [count | flux | emis | sum_redshift | sum_time | disc_count];
+ * counts are held as doubles (exact below 2^53).  The call ADDS into d_hist (zero it first). */
+int kr_reduce_emissivity_dev_f64(const kr_emis_bins* b, const void* d_rays, int64_t n, void* d_hist, void* stream);
+/* imageplane_disc_image.cpp:122-161.  Seven planes of img_nx*img_ny, [ix*img_ny + iy] like Array2D:
+ * nrays(int32), flux, r, phi, enshift, time, emis -- raw sums BEFORE the divisions of :165-174. */
+int kr_reduce_image_f64(const kr_image_bins* b, const kr_ray_f64* rays, int64_t n,
+                        int32_t* nrays, double* flux, double* r, double* phi, double* enshift, double* time,
+                        double* emis, int64_t* disc_count);
+/* d_planes: device buffer of 7*img_nx*img_ny+1 doubles [nrays | flux | r | phi | enshift | time | emis | disc_count],
+ * nrays held as doubles.  ADDS into d_planes. */
+int kr_reduce_image_dev_f64(const kr_image_bins* b, const void* d_rays, int64_t n, void* d_planes, void* stream);
+
+/* ---- device memory helpers for callers without a HIP runtime of their own --------------------- */
+int kr_malloc(void** d_ptr, int64_t bytes);
+int kr_free(void* d_ptr);
+int kr_memcpy_h2d(void* d_dst, const void* h_src, int64_t bytes);
+int kr_memcpy_d2h(void* h_dst, const void* d_src, int64_t bytes);
+int kr_memset(void* d_ptr, int value, int64_t bytes);
+int kr_synchronize(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KR_TRACE_H_ */
