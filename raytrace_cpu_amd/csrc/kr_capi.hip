@@ -1,0 +1,390 @@
+// kr_capi.hip -- the extern "C" surface declared in include/kr_trace.h.
+// Host-pointer entry points stage rays through a private device buffer (H2D, kernels, D2H) so that the
+// caller's rays[] is up to date on return, which is the contract of the reference's member functions.
+// There is no CPU implementation behind any of these: without a HIP device they return KR_ENODEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kr_common.hpp"
+
+namespace kr {
+
+// implemented in kr_post.hip
+int redshift_start_dev(double spin, double V, int reverse, int projradius, void* d, int64_t n, hipStream_t st);
+int redshift_dev(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, hipStream_t st);
+int redshift_dest_dev(double spin, int reverse, void* d, int64_t n, hipStream_t st);
+int range_phi_dev(double lo, double hi, void* d, int64_t n, hipStream_t st);
+int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st);
+int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, hipStream_t st);
+int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, hipStream_t st);
+int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st);
+int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st);
+
+static thread_local std::string g_error;
+
+void set_error(const std::string& msg) { g_error = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line)
+{
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_error = buf;
+    (void) hipGetLastError();
+    return (e == hipErrorOutOfMemory) ? KR_ENOMEM : (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? KR_ENODEVICE : KR_EHIP;
+}
+
+int require_device()
+{
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void) hipGetLastError();
+        g_error = "no HIP device available (libkrtrace has no CPU fallback)";
+        return KR_ENODEVICE;
+    }
+    return KR_OK;
+}
+
+int DeviceBuffer::alloc(size_t bytes)
+{
+    KR_HIP(hipMalloc(&p, bytes ? bytes : 1));
+    return KR_OK;
+}
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+// run `body(d_rays)` on a device copy of a host ray array and copy the array back
+template <typename Body>
+int with_staged_rays(void* rays, int64_t n, size_t ray_bytes, bool copy_in, bool copy_out, kr_stats* stats, Body body)
+{
+    if (n < 0 || (n > 0 && !rays)) { set_error("null rays pointer or negative n"); return KR_EINVAL; }
+    int rc = require_device();
+    if (rc != KR_OK) return rc;
+    if (n == 0) return body(nullptr);
+    DeviceBuffer buf;
+    rc = buf.alloc((size_t) n * ray_bytes);
+    if (rc != KR_OK) return rc;
+    auto t0 = clk::now();
+    if (copy_in) KR_HIP(hipMemcpy(buf.p, rays, (size_t) n * ray_bytes, hipMemcpyHostToDevice));
+    const double h2d = ms_since(t0);
+    rc = body(buf.p);
+    if (rc != KR_OK) return rc;
+    KR_HIP(hipDeviceSynchronize());
+    t0 = clk::now();
+    if (copy_out) KR_HIP(hipMemcpy(rays, buf.p, (size_t) n * ray_bytes, hipMemcpyDeviceToHost));
+    if (stats) { stats->h2d_ms = h2d; stats->d2h_ms = ms_since(t0); }
+    return KR_OK;
+}
+
+}  // namespace
+}  // namespace kr
+
+using namespace kr;
+
+extern "C" {
+
+int kr_abi_version(void) { return KR_ABI_VERSION; }
+const char* kr_last_error(void) { return g_error.c_str(); }
+
+int kr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void) hipGetLastError();
+        set_error("no HIP device available");
+        return KR_ENODEVICE;
+    }
+    return n;
+}
+
+int kr_set_device(int device)
+{
+    KR_HIP(hipSetDevice(device));
+    return KR_OK;
+}
+
+int kr_device_info(int* cus, int* clock_khz, int64_t* hbm_bytes, char* name, int name_len)
+{
+    int rc = require_device();
+    if (rc != KR_OK) return rc;
+    int dev = 0;
+    KR_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    KR_HIP(hipGetDeviceProperties(&prop, dev));
+    if (cus) *cus = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (hbm_bytes) *hbm_bytes = (int64_t) prop.totalGlobalMem;
+    if (name && name_len > 0) {
+        std::snprintf(name, (size_t) name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    return KR_OK;
+}
+
+// Raytracer<T> ctor defaults, raytracer.cpp:12-22 + raytracer.h:19-44; horizon = kerr_horizon(spin), kerr.h:14-20
+void kr_params_default(kr_params* p, double spin)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->spin = spin;
+    p->horizon = 1 + std::sqrt((1 - spin) * (1 + spin));
+    p->precision = KR_PRECISION;
+    p->theta_precision = KR_THETA_PRECISION;
+    p->max_tstep = KR_MAXDT;
+    p->maxtstep_rlim = KR_MAXDT_RLIM;
+    p->max_phistep = KR_MAXDPHI;
+    p->rk45_tol = 1e-8;
+    p->r_max = 1000;
+    p->theta_max = 1.57079632679489661923;
+    p->integrator = KR_EULER;
+    p->stop_kind = KR_STOP_THETA;
+    p->steplim = -1;
+}
+
+// nRays is the int-truncated PRODUCT of doubles (pointsource.cpp:12), n_cosalpha / n_beta the truncated factors (:16-17)
+int64_t kr_pointsource_count(const kr_pointsource* s, int32_t* n_cosalpha, int32_t* n_beta)
+{
+    const int nrays = (int) ((((s->cosalphamax - s->cosalpha0) / s->dcosalpha) + 1) * (((s->betamax - s->beta0) / s->dbeta) + 1));
+    if (n_cosalpha) *n_cosalpha = (int) (((s->cosalphamax - s->cosalpha0) / s->dcosalpha) + 1);
+    if (n_beta) *n_beta = (int) (((s->betamax - s->beta0) / s->dbeta) + 1);
+    return nrays;
+}
+
+// imageplane.cpp:12-14
+int64_t kr_imageplane_count(const kr_imageplane* s, int32_t* nx, int32_t* ny)
+{
+    const int nrays = (int) ((((s->xmax - s->x0) / s->dx) + 1) * (((s->ymax - s->y0) / s->dy) + 1));
+    if (nx) *nx = (int) (((s->xmax - s->x0) / s->dx) + 1);
+    if (ny) *ny = (int) (((s->ymax - s->y0) / s->dy) + 1);
+    return nrays;
+}
+
+// ---- trace ---------------------------------------------------------------------------------------------
+int kr_trace_dev_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, kr_stats* stats)
+{
+    return trace_dev(p, d_rays, n, (hipStream_t) stream, stats, false);
+}
+
+int kr_trace_dev_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, kr_stats* stats)
+{
+    return trace_dev(p, d_rays, n, (hipStream_t) stream, stats, true);
+}
+
+int kr_trace_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, kr_stats* stats)
+{
+    if (!p) { set_error("kr_trace: null params"); return KR_EINVAL; }
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, stats,
+                            [&](void* d) { return trace_dev(p, d, n, nullptr, stats, false); });
+}
+
+int kr_trace_f32(const kr_params* p, kr_ray_f32* rays, int64_t n, kr_stats* stats)
+{
+    if (!p) { set_error("kr_trace: null params"); return KR_EINVAL; }
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return with_staged_rays(rays, n, sizeof(kr_ray_f32), true, true, stats,
+                            [&](void* d) { return trace_dev(p, d, n, nullptr, stats, true); });
+}
+
+// ---- O(N) passes -------------------------------------------------------------------------------------------
+int kr_redshift_start_dev_f64(double spin, double V, int reverse, int projradius, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : redshift_start_dev(spin, V, reverse, projradius, d, n, (hipStream_t) st);
+}
+int kr_redshift_start_f64(double spin, double V, int reverse, int projradius, kr_ray_f64* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
+                            [&](void* d) { return redshift_start_dev(spin, V, reverse, projradius, d, n, nullptr); });
+}
+
+int kr_redshift_dev_f64(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : redshift_dev(spin, V, reverse, projradius, motion, d, n, (hipStream_t) st);
+}
+int kr_redshift_f64(double spin, double V, int reverse, int projradius, int motion, kr_ray_f64* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
+                            [&](void* d) { return redshift_dev(spin, V, reverse, projradius, motion, d, n, nullptr); });
+}
+
+int kr_redshift_dest_dev_f64(double spin, int reverse, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : redshift_dest_dev(spin, reverse, d, n, (hipStream_t) st);
+}
+int kr_redshift_dest_f64(double spin, int reverse, kr_ray_f64* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
+                            [&](void* d) { return redshift_dest_dev(spin, reverse, d, n, nullptr); });
+}
+
+int kr_range_phi_dev_f64(double lo, double hi, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : range_phi_dev(lo, hi, d, n, (hipStream_t) st);
+}
+int kr_range_phi_f64(double lo, double hi, kr_ray_f64* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
+                            [&](void* d) { return range_phi_dev(lo, hi, d, n, nullptr); });
+}
+
+int kr_calculate_momentum_dev_f64(double spin, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : calculate_momentum_dev(spin, d, n, (hipStream_t) st);
+}
+int kr_calculate_momentum_f64(double spin, kr_ray_f64* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
+                            [&](void* d) { return calculate_momentum_dev(spin, d, n, nullptr); });
+}
+
+// ---- sources -----------------------------------------------------------------------------------------------
+int kr_pointsource_init_dev_f64(const kr_pointsource* s, void* d, int64_t n, void* st)
+{
+    if (!s) { set_error("kr_pointsource_init: null spec"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : pointsource_init_dev(s, d, n, (hipStream_t) st);
+}
+int kr_pointsource_init_f64(const kr_pointsource* s, kr_ray_f64* rays, int64_t n)
+{
+    if (!s) { set_error("kr_pointsource_init: null spec"); return KR_EINVAL; }
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), false, true, nullptr,
+                            [&](void* d) { return pointsource_init_dev(s, d, n, nullptr); });
+}
+
+int kr_imageplane_init_dev_f64(const kr_imageplane* s, void* d, int64_t n, void* st)
+{
+    if (!s) { set_error("kr_imageplane_init: null spec"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : imageplane_init_dev(s, d, n, (hipStream_t) st);
+}
+int kr_imageplane_init_f64(const kr_imageplane* s, kr_ray_f64* rays, int64_t n)
+{
+    if (!s) { set_error("kr_imageplane_init: null spec"); return KR_EINVAL; }
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), false, true, nullptr,
+                            [&](void* d) { return imageplane_init_dev(s, d, n, nullptr); });
+}
+
+// ---- reducers ------------------------------------------------------------------------------------------------
+int kr_reduce_emissivity_dev_f64(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, void* st)
+{
+    if (!b || !d_hist) { set_error("kr_reduce_emissivity: null argument"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : reduce_emissivity_dev(b, d, n, d_hist, (hipStream_t) st);
+}
+
+int kr_reduce_emissivity_f64(const kr_emis_bins* b, const kr_ray_f64* rays, int64_t n, int64_t* count, double* flux,
+                             double* emis, double* sum_redshift, double* sum_time, int64_t* disc_count)
+{
+    if (!b || !count || !flux || !emis || !sum_redshift || !sum_time) { set_error("kr_reduce_emissivity: null argument"); return KR_EINVAL; }
+    if (b->nr <= 0) { set_error("kr_reduce_emissivity: nr must be positive"); return KR_EINVAL; }
+    const size_t words = (size_t) 5 * b->nr + 1;
+    std::vector<double> h(words, 0.0);
+    int rc = with_staged_rays((void*) rays, n, sizeof(kr_ray_f64), true, false, nullptr, [&](void* d) {
+        DeviceBuffer hist;
+        int r2 = hist.alloc(words * sizeof(double));
+        if (r2 != KR_OK) return r2;
+        KR_HIP(hipMemset(hist.p, 0, words * sizeof(double)));
+        r2 = reduce_emissivity_dev(b, d, n, hist.p, nullptr);
+        if (r2 != KR_OK) return r2;
+        KR_HIP(hipMemcpy(h.data(), hist.p, words * sizeof(double), hipMemcpyDeviceToHost));
+        return (int) KR_OK;
+    });
+    if (rc != KR_OK) return rc;
+    const int nr = b->nr;
+    for (int i = 0; i < nr; i++) {
+        count[i] = (int64_t) h[i];
+        flux[i] = h[nr + i];
+        emis[i] = h[2 * nr + i];
+        sum_redshift[i] = h[3 * nr + i];
+        sum_time[i] = h[4 * nr + i];
+    }
+    if (disc_count) *disc_count = (int64_t) h[5 * nr];
+    return KR_OK;
+}
+
+int kr_reduce_image_dev_f64(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, void* st)
+{
+    if (!b || !d_planes) { set_error("kr_reduce_image: null argument"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : reduce_image_dev(b, d, n, d_planes, (hipStream_t) st);
+}
+
+int kr_reduce_image_f64(const kr_image_bins* b, const kr_ray_f64* rays, int64_t n, int32_t* nrays, double* flux, double* r,
+                        double* phi, double* enshift, double* time, double* emis, int64_t* disc_count)
+{
+    if (!b || !nrays || !flux || !r || !phi || !enshift || !time || !emis) { set_error("kr_reduce_image: null argument"); return KR_EINVAL; }
+    if (b->img_nx <= 0 || b->img_ny <= 0) { set_error("kr_reduce_image: image size must be positive"); return KR_EINVAL; }
+    const size_t npix = (size_t) b->img_nx * b->img_ny;
+    const size_t words = 7 * npix + 1;
+    std::vector<double> h(words, 0.0);
+    int rc = with_staged_rays((void*) rays, n, sizeof(kr_ray_f64), true, false, nullptr, [&](void* d) {
+        DeviceBuffer planes;
+        int r2 = planes.alloc(words * sizeof(double));
+        if (r2 != KR_OK) return r2;
+        KR_HIP(hipMemset(planes.p, 0, words * sizeof(double)));
+        r2 = reduce_image_dev(b, d, n, planes.p, nullptr);
+        if (r2 != KR_OK) return r2;
+        KR_HIP(hipMemcpy(h.data(), planes.p, words * sizeof(double), hipMemcpyDeviceToHost));
+        return (int) KR_OK;
+    });
+    if (rc != KR_OK) return rc;
+    for (size_t i = 0; i < npix; i++) nrays[i] = (int32_t) h[i];
+    std::memcpy(flux, &h[npix], npix * sizeof(double));
+    std::memcpy(r, &h[2 * npix], npix * sizeof(double));
+    std::memcpy(phi, &h[3 * npix], npix * sizeof(double));
+    std::memcpy(enshift, &h[4 * npix], npix * sizeof(double));
+    std::memcpy(time, &h[5 * npix], npix * sizeof(double));
+    std::memcpy(emis, &h[6 * npix], npix * sizeof(double));
+    if (disc_count) *disc_count = (int64_t) h[7 * npix];
+    return KR_OK;
+}
+
+// ---- memory helpers ------------------------------------------------------------------------------------------
+int kr_malloc(void** d_ptr, int64_t bytes)
+{
+    if (!d_ptr || bytes < 0) { set_error("kr_malloc: bad argument"); return KR_EINVAL; }
+    int rc = require_device();
+    if (rc != KR_OK) return rc;
+    KR_HIP(hipMalloc(d_ptr, (size_t) (bytes ? bytes : 1)));
+    return KR_OK;
+}
+int kr_free(void* d_ptr)
+{
+    KR_HIP(hipFree(d_ptr));
+    return KR_OK;
+}
+int kr_memcpy_h2d(void* d_dst, const void* h_src, int64_t bytes)
+{
+    KR_HIP(hipMemcpy(d_dst, h_src, (size_t) bytes, hipMemcpyHostToDevice));
+    return KR_OK;
+}
+int kr_memcpy_d2h(void* h_dst, const void* d_src, int64_t bytes)
+{
+    KR_HIP(hipMemcpy(h_dst, d_src, (size_t) bytes, hipMemcpyDeviceToHost));
+    return KR_OK;
+}
+int kr_memset(void* d_ptr, int value, int64_t bytes)
+{
+    KR_HIP(hipMemset(d_ptr, value, (size_t) bytes));
+    return KR_OK;
+}
+int kr_synchronize(void* stream)
+{
+    KR_HIP(hipStreamSynchronize((hipStream_t) stream));
+    return KR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,492 @@
+// kr_device.hpp -- device-side Kerr null-geodesic arithmetic for gfx950 (MI355X).
+//
+// One ray per work-item; the whole ray state lives in VGPRs.  Everything here is a pure
+// __device__ function of registers: no memory traffic, no LDS, no cross-lane ops.  The per-step
+// semantics follow the reference propagators (file:line cited per function, paths relative to the
+// reference tree); arithmetic is written with the reference's association so that, built with
+// -ffp-contract=off, a step differs from the CPU result only through the device libm (sin, cos,
+// pow: <= 1-2 ulp vs glibc), never through re-ordering.
+//
+// T = double is the product precision; T = float mirrors the reference's second instantiation
+// (raytracer.cpp:1896-1897).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kr_trace.h"
+
+namespace kr {
+
+#define KR_DEV __device__ __forceinline__
+
+// ---- scalar helpers -------------------------------------------------------------------------
+KR_DEV double kr_abs(double x) { return __builtin_fabs(x); }
+KR_DEV float kr_abs(float x) { return __builtin_fabsf(x); }
+KR_DEV double kr_sqrt(double x) { return __builtin_sqrt(x); }     // IEEE correctly rounded on gfx950 (checked in tests/test_gpu_primitives.py)
+KR_DEV float kr_sqrt(float x) { return __builtin_sqrtf(x); }
+KR_DEV void kr_sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+KR_DEV void kr_sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+KR_DEV double kr_sin(double x) { return ::sin(x); }
+KR_DEV float kr_sin(float x) { return ::sinf(x); }
+KR_DEV double kr_cos(double x) { return ::cos(x); }
+KR_DEV float kr_cos(float x) { return ::cosf(x); }
+KR_DEV double kr_tan(double x) { return ::tan(x); }
+KR_DEV float kr_tan(float x) { return ::tanf(x); }
+KR_DEV double kr_pow(double x, double y) { return ::pow(x, y); }
+KR_DEV float kr_pow(float x, float y) { return ::powf(x, y); }
+KR_DEV double kr_log(double x) { return ::log(x); }
+KR_DEV double kr_acos(double x) { return ::acos(x); }
+KR_DEV double kr_asin(double x) { return ::asin(x); }
+KR_DEV double kr_atan2(double y, double x) { return ::atan2(y, x); }
+// std::max / std::min operand semantics (they decide what a NaN operand does; raytracer.cpp:1512-1533)
+template <typename T> KR_DEV T std_max(T a, T b) { return (a < b) ? b : a; }
+template <typename T> KR_DEV T std_min(T a, T b) { return (b < a) ? b : a; }
+
+template <typename T> struct Lim;
+template <> struct Lim<double> { static KR_DEV double max() { return 1.7976931348623157e308; } };
+template <> struct Lim<float> { static KR_DEV float max() { return 3.402823466e38f; } };
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kPi2 = 1.57079632679489661923;
+
+// ---- per-launch constants (kernarg) -----------------------------------------------------------
+template <typename T> struct TraceConsts {
+    T a, horizon, rlim, thetalim;
+    T precision, theta_precision, max_tstep, maxtstep_rlim, max_phistep, tol;
+    T sp0, sp1, sp2;        // stop_params
+    int32_t steplim;
+    int32_t stop_kind;
+};
+
+// ---- per-lane ray state ---------------------------------------------------------------------
+template <typename T> struct Lane {
+    T t, r, theta, phi;
+    T pt, pr, ptheta, pphi;
+    T k, h, Q;
+    int32_t rdot_sign, thetadot_sign, rdot_flips, eq_cross;
+    int32_t steps;          // steps taken in THIS call (the reference's local `steps`)
+    int32_t status;
+    int32_t steps0;         // rays[i].steps on entry
+    bool r_was_positive, theta_was_positive;   // per-call locals, raytracer.cpp:767-768
+    // RK45 only
+    T step;                 // running step size
+    T theta_eq_prev;
+    T theta_prev;
+    bool in_retry;          // a trial step was rejected: next iteration retries with the same k1
+};
+
+// momentum_from_consts, src/include/kerr.h:300-335
+template <typename T>
+KR_DEV void momentum(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a)
+{
+    T sin_theta, cos_theta;
+    kr_sincos(theta, sin_theta, cos_theta);
+    const T sin2theta = sin_theta * sin_theta;
+    const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
+    const T delta = r * r - 2 * r + a * a;
+    const T rhosq_delta = rhosq * delta;
+
+    pt = (rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h;
+    pt /= rhosq_delta;
+
+    pphi = 2 * a * r * sin2theta * k + (rhosq - 2 * r) * h;
+    pphi /= sin2theta * rhosq_delta;
+
+    const T hcs = h * cos_theta / sin_theta;
+    T thetadotsq = Q + (k * a * cos_theta + hcs) * (k * a * cos_theta - hcs);
+    thetadotsq = thetadotsq / (rhosq * rhosq);
+    ptheta = kr_sqrt(kr_abs(thetadotsq)) * thetadot_sign;
+
+    T rdotsq = k * pt - h * pphi - rhosq * ptheta * ptheta;
+    rdotsq = rdotsq * delta / rhosq;
+    pr = kr_sqrt(kr_abs(rdotsq)) * rdot_sign;
+}
+
+// k1 at the current position with turning-point logic; identical in all five reference propagators
+// (raytracer.cpp:177-222, :805-849, :1086-1130, :1370-1398, :1680-1708).  RK45_ASSOC selects the RK45
+// bodies' association of the phidot denominator ((sin2theta*rhosq)*delta, :1375 vs :818).
+// Returns true when the reference would `continue` (theta turning point: sign flipped, nothing moves).
+template <typename T, bool RK45_ASSOC>
+KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
+{
+    const T r = s.r, theta = s.theta, k = s.k, h = s.h;
+    T sin_theta, cos_theta;
+    kr_sincos(theta, sin_theta, cos_theta);
+    const T sin2theta = sin_theta * sin_theta;
+    const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
+    const T delta = r * r - 2 * r + a * a;
+
+    if (RK45_ASSOC) {
+        s.pt = ((rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h) / (rhosq * delta);
+        s.pphi = (2 * a * r * sin2theta * k + (rhosq - 2 * r) * h) / (sin2theta * rhosq * delta);
+    } else {
+        const T rhosq_delta = rhosq * delta;
+        s.pt = (rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h;
+        s.pt /= rhosq_delta;
+        s.pphi = 2 * a * r * sin2theta * k + (rhosq - 2 * r) * h;
+        s.pphi /= sin2theta * rhosq_delta;
+    }
+
+    const T hcs = h * cos_theta / sin_theta;
+    T thetadotsq = s.Q + (k * a * cos_theta + hcs) * (k * a * cos_theta - hcs);
+    thetadotsq = thetadotsq / (rhosq * rhosq);
+
+    if (thetadotsq < 0 && s.theta_was_positive) {
+        s.thetadot_sign = -s.thetadot_sign;
+        s.theta_was_positive = false;
+        return true;
+    }
+    if (thetadotsq >= 0) s.theta_was_positive = true;
+
+    s.ptheta = kr_sqrt(kr_abs(thetadotsq)) * s.thetadot_sign;
+
+    T rdotsq = k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta;
+    rdotsq = rdotsq * delta / rhosq;
+    if (rdotsq <= 0 && s.r_was_positive) {
+        s.rdot_sign = -s.rdot_sign;
+        s.r_was_positive = false;
+        s.rdot_flips++;
+    } else if (rdotsq > 0) {
+        s.r_was_positive = true;
+    }
+    s.pr = kr_sqrt(kr_abs(rdotsq)) * s.rdot_sign;
+
+    rhosq_o = rhosq;
+    sin2theta_o = sin2theta;
+    return false;
+}
+
+// loop condition of the theta-limit overloads (raytracer.cpp:172, :799, :1362-1364) or of the
+// RayDestination overloads (:1080, :1674)
+template <typename T, bool USE_DEST>
+KR_DEV bool loop_cond(const Lane<T>& s, const TraceConsts<T>& c)
+{
+    bool ok = s.r < c.rlim && s.steps < c.steplim;
+    if (!USE_DEST) {
+        const T tl = c.thetalim;
+        ok = ok && ((tl > 0 && s.theta < tl) || (tl < 0 && s.theta > kr_abs(tl)) || tl == 0);
+    }
+    return ok;
+}
+
+// RayDestination::reached(r, theta, phi, prev_theta): ray_destination.h:90-94 (FlatDisc, through the
+// default crossing-aware overload :52-54), :130-142 (DiscWithISCO), :184-190 (FlatPlane)
+template <typename T>
+KR_DEV bool dest_reached(const TraceConsts<T>& c, T r, T theta, T phi, T prev_theta)
+{
+    if (c.stop_kind == KR_STOP_FLATDISC) {
+        const T tl = c.sp0;
+        if (tl > 0) return theta >= tl;
+        if (tl < 0) return theta <= -tl;
+        return false;
+    }
+    if (c.stop_kind == KR_STOP_DISC_ISCO) {
+        const T r_isco = c.sp0, r_out = c.sp1, tl = c.sp2;
+        if (r < r_isco) return false;
+        if (r_out > 0 && r > r_out) return false;
+        if (tl > 0) return (prev_theta < tl && theta >= tl) || (prev_theta > tl && theta <= tl);
+        if (tl < 0) {
+            const T m = -tl;
+            return (prev_theta > m && theta <= m) || (prev_theta < m && theta >= m);
+        }
+        return false;
+    }
+    // KR_STOP_FLATPLANE
+    const T incl = c.sp0, phi0 = c.sp1, z_s = c.sp2;
+    const T proj = r * (kr_sin(theta) * kr_sin(incl) * kr_cos(phi - phi0) + kr_cos(theta) * kr_cos(incl));
+    return proj <= -z_s;
+}
+
+// RayDestination::step_limit(): ray_destination.h:55-57 (base), :95-101, :143-151
+template <typename T>
+KR_DEV T dest_step_limit(const TraceConsts<T>& c, T r, T theta, T ptheta)
+{
+    T tl;
+    if (c.stop_kind == KR_STOP_FLATDISC) {
+        tl = c.sp0;
+    } else if (c.stop_kind == KR_STOP_DISC_ISCO) {
+        if (r < c.sp0) return Lim<T>::max();
+        if (c.sp1 > 0 && r > c.sp1) return Lim<T>::max();
+        tl = c.sp2;
+    } else {
+        return Lim<T>::max();
+    }
+    if (tl > 0 && ptheta > 0 && theta < tl) return (tl - theta) / ptheta;
+    if (tl < 0 && ptheta < 0 && theta > -tl) return (-tl - theta) / ptheta;
+    return Lim<T>::max();
+}
+
+// polar reflection, raytracer.cpp:282-283 / :914-915 / :1498-1499
+template <typename T>
+KR_DEV void reflect_poles(T& theta, T& phi, int32_t& thetadot_sign)
+{
+    if (theta < T(0)) { theta = -theta; thetadot_sign = -thetadot_sign; phi += T(kPi); }
+    if (theta > T(kPi)) { theta = T(2) * T(kPi) - theta; thetadot_sign = -thetadot_sign; phi += T(kPi); }
+}
+
+template <typename T>
+KR_DEV bool crossed_equator(T before, T after)
+{
+    return ((double) before < kPi2 && (double) after >= kPi2) || ((double) before > kPi2 && (double) after <= kPi2);
+}
+
+// One iteration of the Euler (raytracer.cpp:172-313) or RK4 (:799-943, :1080-1229) loop body.
+// Returns true when the ray has finished (break, or the loop condition no longer holds).
+template <typename T, bool RK4, bool USE_DEST>
+KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
+{
+    const T a = c.a;
+    ++s.steps;
+
+    T rhosq, sin2theta;
+    if (k1_with_flips<T, false>(s, a, rhosq, sin2theta)) return !(s.steps < c.steplim);   // r, theta unchanged
+    const T pt1 = s.pt, pr1 = s.pr, ptheta1 = s.ptheta, pphi1 = s.pphi;
+
+    // step-size heuristic (:224-243 / :855-871 / :1136-1151)
+    T step = kr_abs((s.r - c.horizon) / pr1) / c.precision;
+    if (step > kr_abs(s.theta / ptheta1) / c.precision) step = kr_abs(s.theta / ptheta1) / c.theta_precision;
+    if (c.max_tstep > 0 && s.r < c.maxtstep_rlim && step > kr_abs(c.max_tstep / pt1)) step = kr_abs(c.max_tstep / pt1);
+    if (c.max_phistep > 0 && step > kr_abs(c.max_phistep / pphi1)) step = kr_abs(c.max_phistep / pphi1);
+    if ((double) step < KR_MIN_STEP) step = T(KR_MIN_STEP);
+    if (c.rlim > 0 && s.r + pr1 * step > c.rlim) step = kr_abs((c.rlim - s.r) / pr1);
+    if (!USE_DEST) {
+        if (c.thetalim > 0 && s.theta + ptheta1 * step > c.thetalim) step = kr_abs((c.thetalim - s.theta) / ptheta1);
+    }
+
+    // flags (:264-273 / :874-887); neither ends the ray
+    if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
+    if ((1 - 2 * s.r / rhosq) * pt1 + (2 * a * s.r * sin2theta / rhosq) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
+
+    const T theta_prev = s.theta;
+    if (!RK4) {
+        s.t += pt1 * step;
+        s.r += pr1 * step;
+        s.theta += ptheta1 * step;
+        s.phi += pphi1 * step;
+    } else {
+        // k2..k4 use k1's signs and move only (r, theta)  (:889-905)
+        T pt2, pr2, ptheta2, pphi2;
+        momentum(pt2, pr2, ptheta2, pphi2, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, s.r + (step / 2) * pr1,
+                 s.theta + (step / 2) * ptheta1, a);
+        T acc_t = pt1 + 2 * pt2, acc_phi = pphi1 + 2 * pphi2;
+        T pt3, pr3, ptheta3, pphi3;
+        momentum(pt3, pr3, ptheta3, pphi3, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, s.r + (step / 2) * pr2,
+                 s.theta + (step / 2) * ptheta2, a);
+        acc_t = acc_t + 2 * pt3;
+        acc_phi = acc_phi + 2 * pphi3;
+        T acc_r = pr1 + 2 * pr2 + 2 * pr3, acc_theta = ptheta1 + 2 * ptheta2 + 2 * ptheta3;
+        T pt4, pr4, ptheta4, pphi4;
+        momentum(pt4, pr4, ptheta4, pphi4, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, s.r + step * pr3,
+                 s.theta + step * ptheta3, a);
+        // x += (step/6)(k1 + 2k2 + 2k3 + k4), summed left to right as in :908-912
+        const T w = step / 6;
+        s.t += w * (acc_t + pt4);
+        s.r += w * (acc_r + pr4);
+        s.theta += w * (acc_theta + ptheta4);
+        s.phi += w * (acc_phi + pphi4);
+    }
+    if (crossed_equator(theta_prev, s.theta)) ++s.eq_cross;
+    reflect_poles(s.theta, s.phi, s.thetadot_sign);
+
+    if (s.r <= c.horizon) { s.status |= KR_STATUS_HORIZON; return true; }
+    if (USE_DEST) {
+        if (dest_reached(c, s.r, s.theta, s.phi, theta_prev)) { s.status |= KR_STATUS_DEST; return true; }
+    }
+    return !loop_cond<T, USE_DEST>(s, c);
+}
+
+// ---- RK45 / DOPRI5 (raytracer.cpp:1260-1598, :1600-1894) ----------------------------------------
+template <typename T> struct Dopri {
+    // Butcher tableau, :1316-1330, formed exactly as T(n)/d
+    static constexpr T a21 = T(1) / 5;
+    static constexpr T a31 = T(3) / 40, a32 = T(9) / 40;
+    static constexpr T a41 = T(44) / 45, a42 = T(-56) / 15, a43 = T(32) / 9;
+    static constexpr T a51 = T(19372) / 6561, a52 = T(-25360) / 2187, a53 = T(64448) / 6561, a54 = T(-212) / 729;
+    static constexpr T a61 = T(9017) / 3168, a62 = T(-355) / 33, a63 = T(46732) / 5247, a64 = T(49) / 176, a65 = T(-5103) / 18656;
+    static constexpr T b1 = T(35) / 384, b3 = T(500) / 1113, b4 = T(125) / 192, b5 = T(-2187) / 6784, b6 = T(11) / 84;
+    static constexpr T e1 = T(71) / 57600, e3 = T(-71) / 16695, e4 = T(71) / 1920, e5 = T(-17253) / 339200, e6 = T(22) / 525, e7 = T(-1) / 40;
+};
+
+// Seeds the running step when a ray enters propagate_rk45 (:1341-1359): k1 WITHOUT flip logic, heuristic
+// WITHOUT boundary clips, theta test guarded by |thetadot| > 0 and compared against theta_precision.
+template <typename T>
+KR_DEV void rk45_seed(Lane<T>& s, const TraceConsts<T>& c)
+{
+    const T a = c.a, r = s.r, theta = s.theta, k = s.k, h = s.h;
+    T sin_theta, cos_theta;
+    kr_sincos(theta, sin_theta, cos_theta);
+    const T sin2theta = sin_theta * sin_theta;
+    const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
+    const T delta = r * r - 2 * r + a * a;
+    s.pt = ((rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h) / (rhosq * delta);
+    s.pphi = (2 * a * r * sin2theta * k + (rhosq - 2 * r) * h) / (sin2theta * rhosq * delta);
+    const T hcs = h * cos_theta / sin_theta;
+    const T thetadotsq = (s.Q + (k * a * cos_theta + hcs) * (k * a * cos_theta - hcs)) / (rhosq * rhosq);
+    s.ptheta = kr_sqrt(kr_abs(thetadotsq)) * s.thetadot_sign;
+    const T rdotsq = (k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta) * delta / rhosq;
+    s.pr = kr_sqrt(kr_abs(rdotsq)) * s.rdot_sign;
+
+    T step = kr_abs((r - c.horizon) / s.pr) / c.precision;
+    if (kr_abs(s.ptheta) > 0 && step > kr_abs(theta / s.ptheta) / c.theta_precision) step = kr_abs(theta / s.ptheta) / c.theta_precision;
+    if (c.max_tstep > 0 && r < c.maxtstep_rlim && step > kr_abs(c.max_tstep / s.pt)) step = kr_abs(c.max_tstep / s.pt);
+    if (c.max_phistep > 0 && step > kr_abs(c.max_phistep / s.pphi)) step = kr_abs(c.max_phistep / s.pphi);
+    if ((double) step < KR_MIN_STEP) step = T(KR_MIN_STEP);
+    s.step = step;
+    s.theta_eq_prev = theta;
+    s.in_retry = false;
+}
+
+// One wave iteration of RK45 = at most one TRIAL step per lane.  The reference nests a retry loop inside
+// the outer step (:1438-1541); here a rejected lane keeps its k1 (s.pt..s.pphi hold k1 until a trial is
+// accepted) and retries on the next iteration, so a rejection never stalls the other 63 lanes.
+// attempts/rejects are per-lane counters.  Returns true when the ray has finished.
+template <typename T, bool USE_DEST>
+KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& rejects)
+{
+    using D = Dopri<T>;
+    const T a = c.a;
+
+    if (!s.in_retry) {
+        ++s.steps;
+        T rhosq, sin2theta;
+        if (k1_with_flips<T, true>(s, a, rhosq, sin2theta)) return !(s.steps < c.steplim);
+        // flags (:1403-1410): same rhosq / sin2theta values as k1's
+        if (s.pt <= 0) s.status |= KR_STATUS_ERGO;
+        if ((1 - 2 * s.r / rhosq) * s.pt + (2 * a * s.r * sin2theta / rhosq) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
+        // outer cap (:1421-1434): horizon / phi / t, no MIN_STEP floor afterwards
+        T step_max = kr_abs((s.r - c.horizon) / s.pr) / c.precision;
+        if (c.max_phistep > 0) {
+            const T step_phi = kr_abs(c.max_phistep / s.pphi);
+            if (step_phi < step_max) step_max = step_phi;
+        }
+        if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
+            const T step_t = kr_abs(c.max_tstep / s.pt);
+            if (step_t < step_max) step_max = step_t;
+        }
+        if (s.step > step_max) s.step = step_max;
+        s.theta_prev = s.theta;
+    }
+    const T pt1 = s.pt, pr1 = s.pr, ptheta1 = s.ptheta, pphi1 = s.pphi;
+    const T r = s.r, theta = s.theta;
+
+    // trial step with boundary clamps (:1442-1453 / :1745-1755)
+    T h_try = s.step;
+    bool clamped = false;
+    if (!USE_DEST) {
+        if (c.thetalim > 0 && theta + ptheta1 * h_try > c.thetalim) {
+            const T h_th = kr_abs((c.thetalim - theta) / ptheta1);
+            if (h_th < h_try) { h_try = h_th; clamped = true; }
+        }
+    } else {
+        if (c.rlim > 0 && r + pr1 * h_try > c.rlim) { h_try = kr_abs((c.rlim - r) / pr1); clamped = true; }
+        const T h_dest = dest_step_limit(c, r, theta, ptheta1);
+        if (h_dest < h_try) { h_try = h_dest; clamped = true; }
+    }
+    ++attempts;
+
+    // stages 2..6; the b- and e-weighted sums are accumulated in stage order, which is the reference's
+    // left-to-right order (:1493-1496, :1508-1509), so only (pr_i, ptheta_i) stay live across stages
+    T pt_i, pphi_i;
+    T pr2, ptheta2, pr3, ptheta3, pr4, ptheta4, pr5, ptheta5, pr6, ptheta6;
+    T sum_t = D::b1 * pt1, sum_phi = D::b1 * pphi1;
+
+    momentum(pt_i, pr2, ptheta2, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r + h_try * D::a21 * pr1,
+             theta + h_try * D::a21 * ptheta1, a);
+
+    momentum(pt_i, pr3, ptheta3, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
+             theta + h_try * (D::a31 * ptheta1 + D::a32 * ptheta2), a);
+    sum_t = sum_t + D::b3 * pt_i;
+    sum_phi = sum_phi + D::b3 * pphi_i;
+
+    momentum(pt_i, pr4, ptheta4, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign,
+             r + h_try * (D::a41 * pr1 + D::a42 * pr2 + D::a43 * pr3),
+             theta + h_try * (D::a41 * ptheta1 + D::a42 * ptheta2 + D::a43 * ptheta3), a);
+    sum_t = sum_t + D::b4 * pt_i;
+    sum_phi = sum_phi + D::b4 * pphi_i;
+
+    momentum(pt_i, pr5, ptheta5, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign,
+             r + h_try * (D::a51 * pr1 + D::a52 * pr2 + D::a53 * pr3 + D::a54 * pr4),
+             theta + h_try * (D::a51 * ptheta1 + D::a52 * ptheta2 + D::a53 * ptheta3 + D::a54 * ptheta4), a);
+    sum_t = sum_t + D::b5 * pt_i;
+    sum_phi = sum_phi + D::b5 * pphi_i;
+
+    momentum(pt_i, pr6, ptheta6, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign,
+             r + h_try * (D::a61 * pr1 + D::a62 * pr2 + D::a63 * pr3 + D::a64 * pr4 + D::a65 * pr5),
+             theta + h_try * (D::a61 * ptheta1 + D::a62 * ptheta2 + D::a63 * ptheta3 + D::a64 * ptheta4 + D::a65 * ptheta5), a);
+    sum_t = sum_t + D::b6 * pt_i;
+    sum_phi = sum_phi + D::b6 * pphi_i;
+
+    // 5th-order solution (:1493-1499); the polar reflection mutates thetadot_sign even if the trial is rejected
+    T r_new = r + h_try * (D::b1 * pr1 + D::b3 * pr3 + D::b4 * pr4 + D::b5 * pr5 + D::b6 * pr6);
+    T theta_new = theta + h_try * (D::b1 * ptheta1 + D::b3 * ptheta3 + D::b4 * ptheta4 + D::b5 * ptheta5 + D::b6 * ptheta6);
+    T t_new = s.t + h_try * sum_t;
+    T phi_new = s.phi + h_try * sum_phi;
+    reflect_poles(theta_new, phi_new, s.thetadot_sign);
+
+    T pt7, pr7, ptheta7, pphi7;
+    momentum(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a);
+
+    // error norm over (r, theta) and the step controller (:1508-1519)
+    const T err_r = h_try * (D::e1 * pr1 + D::e3 * pr3 + D::e4 * pr4 + D::e5 * pr5 + D::e6 * pr6 + D::e7 * pr7);
+    const T err_theta = h_try * (D::e1 * ptheta1 + D::e3 * ptheta3 + D::e4 * ptheta4 + D::e5 * ptheta5 + D::e6 * ptheta6 + D::e7 * ptheta7);
+    const T sc_r = c.tol * (T(1) + std_max(kr_abs(r), kr_abs(r_new)));
+    const T sc_theta = c.tol * (T(1) + std_max(kr_abs(theta), kr_abs(theta_new)));
+    const T err_norm = kr_sqrt(T(0.5) * ((err_r / sc_r) * (err_r / sc_r) + (err_theta / sc_theta) * (err_theta / sc_theta)));
+
+    T fac = T(0.9) * kr_pow(T(1) / std_max(err_norm, T(1e-10)), T(0.2));
+    fac = std_max(T(0.1), std_min(T(5.0), fac));
+    const T step_new = h_try * fac;
+
+    bool commit = false;
+    if (err_norm <= T(1)) {
+        if (!clamped) s.step = std_max(step_new, T(KR_MIN_STEP));
+        commit = true;
+    } else {
+        ++rejects;
+        s.step = std_max(step_new, T(KR_MIN_STEP));
+        if (s.step <= T(KR_MIN_STEP)) {
+            commit = true;                       // cannot shrink further: force-accept (:1533-1539)
+        } else if (err_norm != err_norm) {
+            // NaN error norm: the reference never leaves its retry loop here.  End the ray (documented extension).
+            s.status |= KR_STATUS_NAN;
+            s.in_retry = false;
+            return true;
+        }
+    }
+    if (!commit) {
+        s.in_retry = true;
+        return false;
+    }
+    s.in_retry = false;
+    s.t = t_new; s.r = r_new; s.theta = theta_new; s.phi = phi_new;
+    s.pt = pt7; s.pr = pr7; s.ptheta = ptheta7; s.pphi = pphi7;
+
+    if (crossed_equator(s.theta_eq_prev, s.theta)) ++s.eq_cross;   // once per accepted outer step (:1542-1544)
+    s.theta_eq_prev = s.theta;
+
+    if (s.r <= c.horizon) { s.status |= KR_STATUS_HORIZON; return true; }
+    if (USE_DEST) {
+        if (dest_reached(c, s.r, s.theta, s.phi, s.theta_prev)) { s.status |= KR_STATUS_DEST; return true; }
+    }
+    return !loop_cond<T, USE_DEST>(s, c);
+}
+
+// Epilogue shared by all propagators (raytracer.cpp:315-339, :945-969, :1231-1253, :1574-1597, :1872-1893):
+// final status bits and the value of rays[i].steps to store.
+template <typename T, bool USE_DEST>
+KR_DEV int32_t finish_status(Lane<T>& s, const TraceConsts<T>& c)
+{
+    if (s.steps >= c.steplim)
+        s.status |= KR_STATUS_STEPLIM;
+    else if (s.r >= c.rlim)
+        s.status |= KR_STATUS_RLIM;
+    else if (!USE_DEST && ((c.thetalim > 0 && s.theta >= c.thetalim) || (c.thetalim < 0 && s.theta <= kr_abs(c.thetalim))))
+        s.status |= KR_STATUS_DEST;
+    int32_t out_steps = s.steps0;
+    if (s.steps > 0) out_steps += s.steps;
+    if (s.status & KR_STATUS_STEPLIM) out_steps = -out_steps;
+    return out_steps;
+}
+
+}  // namespace kr

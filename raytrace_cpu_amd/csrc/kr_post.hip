@@ -1,0 +1,464 @@
+// kr_post.hip -- the O(N) passes either side of the trace kernel, one ray per work-item:
+//   ray sources     PointSource / ImagePlane ctors            (pointsource.cpp:11-64, imageplane.cpp:11-121)
+//   redshift_start  emitted energy before the trace            (raytracer.cpp:342-417)
+//   redshift        received/emitted energy ratio after it     (raytracer.cpp:420-600)
+//   range_phi, calculate_momentum                               (raytracer.cpp:603-622, :704-753)
+//   reducers        emissivity radial histogram, disc image    (emissivity.cpp:96-126, imageplane_disc_image.cpp:122-161)
+// The reference runs these as serial host loops over rays[]; here they are streaming kernels over the same
+// 144-B records (HBM-bound: 144 B read + <=16 B written per ray), so that at 1e7..1e8 rays the whole
+// source -> trace -> redshift -> histogram pipeline can stay resident in HBM and only the histogram leaves.
+// Histograms are accumulated per workgroup in LDS (ds_add_f64) and flushed with one global atomic per bin.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "kr_common.hpp"
+#include "kr_device.hpp"
+
+namespace kr {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int grid_for(int64_t n, int cap_blocks = 256 * 16)
+{
+    const int64_t b = (n + kBlock - 1) / kBlock;
+    return (int) std::max<int64_t>(1, std::min<int64_t>(b, cap_blocks));
+}
+
+// Kerr metric in the (e2nu, e2psi, omega) form used throughout the reference
+// (raytracer.cpp:370-388, :491-509, :564-582, :632-639)
+struct Metric {
+    double rhosq, delta, sigmasq, e2nu, e2psi, omega;
+    double g00, g03, g11, g22, g33;
+};
+
+KR_DEV Metric kerr_metric(double r, double theta, double a)
+{
+    Metric m;
+    const double st = kr_sin(theta), ct = kr_cos(theta);
+    m.rhosq = r * r + (a * ct) * (a * ct);
+    m.delta = r * r - 2 * r + a * a;
+    m.sigmasq = (r * r + a * a) * (r * r + a * a) - a * a * m.delta * st * st;
+    m.e2nu = m.rhosq * m.delta / m.sigmasq;
+    m.e2psi = m.sigmasq * st * st / m.rhosq;
+    m.omega = 2 * a * r / m.sigmasq;
+    m.g00 = m.e2nu - m.omega * m.omega * m.e2psi;
+    m.g03 = m.omega * m.e2psi;
+    m.g11 = -m.rhosq / m.delta;
+    m.g22 = -m.rhosq;
+    m.g33 = -m.e2psi;
+    return m;
+}
+
+// sum_ij g[i][j] * et[i] * p[j] over all 16 entries in row-major order, zeros included, exactly like the
+// reference loops (raytracer.cpp:412-415, :547-550): a 0 * inf or 0 * NaN term must poison the sum the same way.
+KR_DEV double energy_dot(const Metric& m, const double* et, const double* p)
+{
+    const double g[16] = {m.g00, 0, 0, m.g03, 0, m.g11, 0, 0, 0, 0, m.g22, 0, m.g03, 0, 0, m.g33};
+    double e = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) e += g[i * 4 + j] * et[i] * p[j];
+    return e;
+}
+
+KR_DEV double keplerian_V(double a, double r, double theta, bool projradius)
+{
+    if (projradius) return 1 / (a + r * kr_sin(theta) * kr_sqrt(r * kr_sin(theta)));
+    return 1 / (a + r * kr_sqrt(r));
+}
+
+// ---- redshift_start (raytracer.cpp:342-417) ------------------------------------------------------------
+// V is a by-value parameter that the reference's loop overwrites when it equals -1, so the orbital velocity
+// computed at the FIRST record (index 0, valid or not) is used for every ray.
+__global__ void __launch_bounds__(kBlock)
+redshift_start_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double V, int reverse, int projradius)
+{
+    const double a = reverse ? -1 * spin : spin;
+    if (V == -1) V = keplerian_V(a, rays[0].r, rays[0].theta, projradius != 0);
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        kr_ray_f64* ray = &rays[i];
+        const double r = ray->r, theta = ray->theta;
+        const Metric m = kerr_metric(r, theta, a);
+        const double et[4] = {(1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu), 0, 0,
+                              (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu)};
+        double p[4];
+        momentum<double>(p[0], p[1], p[2], p[3], ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, r, theta, spin);
+        if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
+        ray->emit = energy_dot(m, et, p);
+    }
+}
+
+// ---- redshift(V, ...) (raytracer.cpp:420-447, :480-553) ----------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+redshift_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double V_in, int reverse, int projradius, int motion)
+{
+    const double a = reverse ? -1 * spin : spin;
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        kr_ray_f64* ray = &rays[i];
+        const double r = ray->r, theta = ray->theta;
+        const Metric m = kerr_metric(r, theta, a);
+        double V = V_in;
+        double et[4] = {0, 0, 0, 0};
+        if (motion == 0) {
+            if (V == -1) V = keplerian_V(a, r, theta, projradius != 0);
+            et[0] = (1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
+            et[3] = (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
+        } else if (motion == 1) {
+            if (V < 0) V = kr_abs(V) * (r * r - 2 * r + spin + spin) / (r * r + spin * spin);   // sic, :531
+            et[0] = 1. / kr_sqrt(m.g00 + m.g11 * V * V);
+            et[1] = V * et[0];
+        }
+        double p[4];
+        momentum<double>(p[0], p[1], p[2], p[3], ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, r, theta, spin);
+        if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
+        const double recv = energy_dot(m, et, p);
+        ray->redshift = reverse ? recv / ray->emit : ray->emit / recv;
+    }
+}
+
+// ---- redshift(RayDestination*, ...) with the default four_velocity (raytracer.cpp:450-477, :556-600;
+//      ray_destination.h:59-78) -----------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+redshift_dest_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, int reverse)
+{
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        kr_ray_f64* ray = &rays[i];
+        const double r = ray->r, theta = ray->theta;
+        const Metric m = kerr_metric(r, theta, spin);
+        const double V = 1 / (spin + r * kr_sqrt(r));
+        const double gamma_factor = 1 / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
+        const double et[4] = {gamma_factor / kr_sqrt(m.e2nu), 0, 0, gamma_factor * V / kr_sqrt(m.e2nu)};
+        double p[4];
+        momentum<double>(p[0], p[1], p[2], p[3], ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, r, theta, spin);
+        if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
+        const double recv = energy_dot(m, et, p);
+        ray->redshift = reverse ? recv / ray->emit : ray->emit / recv;
+    }
+}
+
+// ---- range_phi (raytracer.cpp:603-622): repeated +-2pi like the reference, so the result is bit-identical ----
+__global__ void __launch_bounds__(kBlock) range_phi_kernel(kr_ray_f64* __restrict__ rays, long long n, double lo, double hi)
+{
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        double phi = rays[i].phi;
+        if (kr_abs(phi) > 1000 || phi != phi || !(rays[i].steps > 0)) continue;
+        while (phi >= hi) phi -= 2 * kPi;
+        while (phi < lo) phi += 2 * kPi;
+        rays[i].phi = phi;
+    }
+}
+
+// ---- calculate_momentum (raytracer.cpp:704-753) ---------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) calculate_momentum_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin)
+{
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        kr_ray_f64* ray = &rays[i];
+        double pt, pr, ptheta, pphi;
+        momentum<double>(pt, pr, ptheta, pphi, ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, ray->r, ray->theta, spin);
+        ray->pt = pt; ray->pr = pr; ray->ptheta = ptheta; ray->pphi = pphi;
+    }
+}
+
+// ---- PointSource ctor: Raytracer ctor (steps=-1, status=0, raytracer.cpp:45-49) + init_pointsource
+//      (pointsource.cpp:30-64) + calculate_constants (raytracer.cpp:625-676).  Fields the reference leaves
+//      indeterminate are zeroed. ------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, int n_cosalpha, int n_beta)
+{
+    const long long n_grid = (long long) n_cosalpha * n_beta;
+    for (long long ix = blockIdx.x * (long long) kBlock + threadIdx.x; ix < n; ix += (long long) gridDim.x * kBlock) {
+        kr_ray_f64 ray;
+        memset(&ray, 0, sizeof(ray));
+        ray.steps = -1;
+        if (ix < n_grid) {
+            const int i = (int) (ix / n_beta), j = (int) (ix % n_beta);
+            const double cosalpha = s.cosalpha0 + i * s.dcosalpha;
+            const double beta = s.beta0 + j * s.dbeta;
+            if (!(cosalpha >= s.cosalphamax || beta >= s.betamax)) {
+                const double alpha = kr_acos(cosalpha);
+                ray.alpha = cosalpha;      // sic: cos(alpha), pointsource.cpp:48
+                ray.beta = beta;
+                ray.t = s.pos[0]; ray.r = s.pos[1]; ray.theta = s.pos[2]; ray.phi = s.pos[3];
+                ray.steps = 0;
+
+                const double spin = s.spin, V = s.V, E = s.E;
+                const double r = ray.r, th = ray.theta;
+                const double st = kr_sin(th), ct = kr_cos(th);
+                const double rhosq = r * r + (spin * ct) * (spin * ct);
+                const double delta = r * r - 2 * r + spin * spin;
+                const double sigmasq = (r * r + spin * spin) * (r * r + spin * spin) - spin * spin * delta * st * st;
+                const double e2nu = rhosq * delta / sigmasq;
+                const double e2psi = sigmasq * st * st / rhosq;
+                const double omega = 2 * spin * r / sigmasq;
+
+                const double et0 = (1 / kr_sqrt(e2nu)) / kr_sqrt(1 - (V - omega) * (V - omega) * e2psi / e2nu);
+                const double et3 = (1 / kr_sqrt(e2nu)) * V / kr_sqrt(1 - (V - omega) * (V - omega) * e2psi / e2nu);
+                const double e10 = (V - omega) * kr_sqrt(e2psi / e2nu) / kr_sqrt(e2nu - (V - omega) * (V - omega) * e2psi);
+                const double e13 = (1 / kr_sqrt(e2nu * e2psi)) * (e2nu + V * omega * e2psi - omega * omega * e2psi) /
+                                   kr_sqrt(e2nu - (V - omega) * (V - omega) * e2psi);
+                const double e22 = -1 / kr_sqrt(rhosq);
+                const double e31 = kr_sqrt(delta / rhosq);
+
+                const double rp0 = E, rp1 = E * kr_sin(alpha) * kr_cos(beta), rp2 = E * kr_sin(alpha) * kr_sin(beta), rp3 = E * kr_cos(alpha);
+                const double tdot = rp0 * et0 + rp1 * e10;
+                const double phidot = rp0 * et3 + rp1 * e13;
+                const double rdot = rp3 * e31;
+                const double thetadot = rp2 * e22;
+
+                ray.k = (1 - 2 * r / rhosq) * tdot + (2 * spin * r * st * st / rhosq) * phidot;
+                double h = phidot * ((r * r + spin * spin) * (r * r + spin * spin * ct * ct - 2 * r) * st * st + 2 * spin * spin * r * st * st * st * st);
+                h = h - 2 * spin * r * ray.k * st * st;
+                h = h / (r * r + spin * spin * ct * ct - 2 * r);
+                ray.h = h;
+                const double tt = kr_tan(th);
+                ray.Q = rhosq * rhosq * thetadot * thetadot - (spin * ray.k * ct + h / tt) * (spin * ray.k * ct - h / tt);
+                ray.rdot_sign = (rdot >= 0) ? 1 : -1;
+                ray.thetadot_sign = (thetadot > 0) ? 1 : -1;
+            }
+        }
+        rays[ix] = ray;
+    }
+}
+
+// ---- ImagePlane ctor + init_image_plane (imageplane.cpp:11-121) ---------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny)
+{
+    const long long n_grid = (long long) Nx * Ny;
+    const double a = -1 * s.spin;                       // imageplane.cpp:12
+    const double D = s.dist, incl = s.inc_deg * kPi / 180, phi0 = s.phi0;
+    for (long long ix = blockIdx.x * (long long) kBlock + threadIdx.x; ix < n; ix += (long long) gridDim.x * kBlock) {
+        kr_ray_f64 ray;
+        memset(&ray, 0, sizeof(ray));
+        ray.steps = -1;
+        if (ix < n_grid) {
+            const int i = (int) (ix / Ny), j = (int) (ix % Ny);
+            const double x = s.x0 + i * s.dy;            // sic: dy, imageplane.cpp:43
+            const double y = s.y0 + j * s.dy;
+            const double si = kr_sin(incl), ci = kr_cos(incl);
+
+            const double r = kr_sqrt(D * D + x * x + y * y);
+            const double theta = kr_acos((D * ci + y * si) / r);
+            const double phi = phi0 + kr_atan2(x, D * si - y * ci);
+
+            const double pr = D / r;
+            const double ptheta = kr_sin(kr_acos(D / r)) / r;
+            const double pphi = x * si / (x * x + (D * si - y * ci) * (D * si - y * ci));
+
+            const double st = kr_sin(theta), ct = kr_cos(theta);
+            const double rhosq = r * r + (a * ct) * (a * ct);
+            const double delta = r * r - 2 * r + a * a;
+            const double sigmasq = (r * r + a * a) * (r * r + a * a) - a * a * delta * st * st;
+            const double e2nu = rhosq * delta / sigmasq;
+            const double e2psi = sigmasq * st * st / rhosq;
+            const double omega = 2 * a * r / sigmasq;
+            const double g00 = e2nu - omega * omega * e2psi, g03 = omega * e2psi, g11 = -rhosq / delta, g22 = -rhosq, g33 = -e2psi;
+
+            const double A = g00, B = 2 * g03 * pphi;
+            const double Cq = g11 * pr * pr + g22 * ptheta * ptheta + g33 * pphi * pphi;
+            double pt = (-B + kr_sqrt(B * B - 4 * A * Cq)) / (2 * A);
+            if (pt < 0) pt = (-B - kr_sqrt(B * B - 4 * A * Cq)) / (2 * A);
+
+            ray.t = 0; ray.r = r; ray.theta = theta; ray.phi = phi;
+            ray.pt = pt; ray.pr = pr; ray.ptheta = ptheta; ray.pphi = pphi;
+            ray.rdot_sign = -1;
+            ray.k = 1;                                   // calculate_constants_from_p's k/h/Q are overwritten, :100-113
+
+            const double b = kr_sqrt(x * x + y * y);
+            double beta = kr_asin(y / b);
+            if (x < 0) beta = kPi - beta;
+            const double h = -1. * b * si * kr_cos(beta);
+            const double ltheta = b * kr_sin(beta);
+            const double tt = kr_tan(theta);
+            ray.h = h;
+            ray.Q = (ltheta * ltheta) - (a * ct) * (a * ct) + ((h / tt)) * ((h / tt));
+            ray.thetadot_sign = (ltheta >= 0) ? 1 : -1;
+            ray.steps = 0;
+            ray.alpha = x;
+            ray.beta = y;
+        }
+        rays[ix] = ray;
+    }
+}
+
+// ---- emissivity reducer (emissivity.cpp:96-126) -----------------------------------------------------------
+// d_hist layout: [count(nr) | flux(nr) | emis(nr) | sum_redshift(nr) | sum_time(nr) | disc_count(1)], doubles.
+// LDS holds one private copy per workgroup when it fits (5*nr+1 doubles); flushed with global f64 atomics.
+constexpr int kMaxLdsBins = 1024;
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(kBlock)
+reduce_emissivity_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_emis_bins b, double* __restrict__ hist)
+{
+    __shared__ double lds[USE_LDS ? (5 * kMaxLdsBins + 1) : 1];
+    const int nr = b.nr;
+    const int words = 5 * nr + 1;
+    if (USE_LDS) {
+        for (int w = threadIdx.x; w < words; w += kBlock) lds[w] = 0;
+        __syncthreads();
+    }
+    double* acc = USE_LDS ? lds : hist;
+    const double log_dr = kr_log(b.dr);
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        const kr_ray_f64* ray = &rays[i];
+        if (!(ray->steps > 0)) continue;
+        const double r = ray->r, g = ray->redshift;
+        const double z = r * kr_cos(ray->theta);         // cartesian(), kerr.h:55
+        if (z < 1E-2 && g > 0 && r >= b.r_isco) {
+            const int ir = b.logbin ? (int) (kr_log(r / b.r_min) / log_dr) : (int) ((r - b.r_min) / b.dr);
+            if (ir >= 0 && ir < nr) {
+                atomicAdd(&acc[ir], 1.0);
+                atomicAdd(&acc[nr + ir], 1 / (b.num_primary_rays * kr_pow(g, 1.0)));
+                atomicAdd(&acc[2 * nr + ir], 1 / kr_pow(g, b.gamma));
+                atomicAdd(&acc[3 * nr + ir], g);
+                atomicAdd(&acc[4 * nr + ir], ray->t);
+            }
+            atomicAdd(&acc[5 * nr], 1.0);
+        }
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int w = threadIdx.x; w < words; w += kBlock)
+            if (lds[w] != 0) atomicAdd(&hist[w], lds[w]);
+    }
+}
+
+// ---- image reducer (imageplane_disc_image.cpp:20-28, :122-161) -------------------------------------------------
+KR_DEV double powerlaw3(double r, double q1, double rb1, double q2, double rb2, double q3)
+{
+    if (r < rb1) return kr_pow(r, -1 * q1);
+    else if (r < rb2) return kr_pow(rb1, q2 - q1) * kr_pow(r, -1 * q2);
+    else return kr_pow(rb1, q2 - q1) * kr_pow(rb2, q3 - q2) * kr_pow(r, -1 * q3);
+}
+
+// d_planes layout: [nrays | flux | r | phi | enshift | time | emis](npix each) + disc_count(1), doubles.
+// A ray lands in one pixel and the ray grid is about the pixel grid, so contention is low: global f64 atomics.
+__global__ void __launch_bounds__(kBlock)
+reduce_image_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_image_bins b, double* __restrict__ planes)
+{
+    const long long npix = (long long) b.img_nx * b.img_ny;
+    unsigned long long hits = 0;
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        const kr_ray_f64* ray = &rays[i];
+        if (!(ray->steps > 0)) continue;
+        const double r = ray->r, g = ray->redshift;
+        const double z = r * kr_cos(ray->theta);
+        if (z < 1E-2 && r >= b.r_isco && r < b.r_disc && g > 0) {
+            int ix = (int) ((ray->alpha - b.x0) / b.img_dx);
+            int iy = (int) ((ray->beta - b.y0) / b.img_dy);
+            if (b.flip_image) iy = b.img_ny - iy - 1;
+            if (ix >= 0 && ix < b.img_nx && iy >= 0 && iy < b.img_ny) {
+                const long long px = (long long) ix * b.img_ny + iy;
+                const double e = powerlaw3(r, b.q1, b.rb1, b.q2, b.rb2, b.q3);
+                atomicAdd(&planes[px], 1.0);
+                atomicAdd(&planes[npix + px], e / kr_pow(g, 3.0));
+                atomicAdd(&planes[2 * npix + px], r);
+                atomicAdd(&planes[3 * npix + px], ray->phi);
+                atomicAdd(&planes[4 * npix + px], 1. / g);
+                atomicAdd(&planes[5 * npix + px], ray->t);
+                atomicAdd(&planes[6 * npix + px], e);
+                ++hits;
+            }
+        }
+    }
+    if (hits) atomicAdd(&planes[7 * npix], (double) hits);
+}
+
+}  // namespace
+
+// ---- launchers (device pointers) ---------------------------------------------------------------------------
+#define KR_LAUNCH_CHECK() KR_HIP(hipGetLastError())
+
+int redshift_start_dev(double spin, double V, int reverse, int projradius, void* d, int64_t n, hipStream_t st)
+{
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(redshift_start_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, V, reverse, projradius);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int redshift_dev(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, hipStream_t st)
+{
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(redshift_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, V, reverse, projradius, motion);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int redshift_dest_dev(double spin, int reverse, void* d, int64_t n, hipStream_t st)
+{
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(redshift_dest_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, reverse);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int range_phi_dev(double lo, double hi, void* d, int64_t n, hipStream_t st)
+{
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(range_phi_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, lo, hi);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st)
+{
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(calculate_momentum_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, hipStream_t st)
+{
+    int32_t nc = 0, nb = 0;
+    const int64_t need = kr_pointsource_count(s, &nc, &nb);
+    if (n < need) { set_error("kr_pointsource_init: n smaller than kr_pointsource_count()"); return KR_EINVAL; }
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(pointsource_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nc, nb);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, hipStream_t st)
+{
+    int32_t nx = 0, ny = 0;
+    const int64_t need = kr_imageplane_count(s, &nx, &ny);
+    if (n < need) { set_error("kr_imageplane_init: n smaller than kr_imageplane_count()"); return KR_EINVAL; }
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(imageplane_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nx, ny);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st)
+{
+    if (b->nr <= 0) { set_error("kr_reduce_emissivity: nr must be positive"); return KR_EINVAL; }
+    if (n <= 0) return KR_OK;
+    // few, fat workgroups: every workgroup flushes 5*nr+1 atomics, so keep the flush traffic below the ray traffic
+    const int grid = grid_for(n, 256 * 4);
+    if (b->nr <= kMaxLdsBins)
+        hipLaunchKernelGGL(reduce_emissivity_kernel<true>, dim3(grid), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_hist);
+    else
+        hipLaunchKernelGGL(reduce_emissivity_kernel<false>, dim3(grid), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_hist);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st)
+{
+    if (b->img_nx <= 0 || b->img_ny <= 0) { set_error("kr_reduce_image: image size must be positive"); return KR_EINVAL; }
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(reduce_image_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_planes);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+}  // namespace kr

@@ -1,0 +1,296 @@
+// kr_trace.hip -- the hot path: Raytracer<T>::run_raytrace (reference raytracer.cpp:63-127, :972-1034)
+// as a persistent gfx950 kernel.
+//
+// Mapping onto the hardware
+//   * one ray per lane, all ray state in VGPRs, metric terms recomputed every evaluation; no LDS, no MFMA
+//     (a latency-bound scalar fp64 ODE, SURVEY.md 8d: bound = fp64 VALU, ~0.5 B of HBM traffic per step);
+//   * rays live in HBM as the reference's own 144-B (84-B) AoS records; a lane touches its record exactly
+//     twice (load on entry, store on exit) -> 288 B per ray, irrelevant next to ~450 steps x ~1200 instructions;
+//   * divergence: rays need 60 ... 100 000 steps.  Waves are persistent: a lane whose ray has ended writes it
+//     back and, through one wave-aggregated atomicAdd on a global queue head (ballot + popcount), pulls the
+//     next unprocessed ray, so a wave never idles on its slowest ray while work is left.  One loop iteration =
+//     one integration step (RK45: one trial step) for every lane that holds a ray;
+//   * the grid is sized to the device (CUs x resident waves), not to n.
+//
+// Work-queue exit: every wave leaves the loop once the queue head has passed n AND none of its lanes holds a
+// ray; every ray ends after at most steplim iterations (steps is incremented on every path through a step,
+// and RK45 retries either shrink the step to MIN_STEP and force-accept, or end the ray on a NaN error norm).
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+#include "kr_common.hpp"
+#include "kr_device.hpp"
+
+namespace kr {
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 independent waves per workgroup, no barriers
+constexpr int kCounters = 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects
+
+template <typename T> struct RayOf;
+template <> struct RayOf<double> { using type = kr_ray_f64; };
+template <> struct RayOf<float> { using type = kr_ray_f32; };
+
+// ---- AoS record <-> registers -----------------------------------------------------------------
+KR_DEV void load_ray(const kr_ray_f64* p, Lane<double>& s)
+{
+    const double2* d = reinterpret_cast<const double2*>(p);      // 144-B records, 16-B aligned
+    const double2 a0 = d[0], a1 = d[1], a2 = d[2], a3 = d[3], a4 = d[4];
+    s.t = a0.x; s.r = a0.y; s.theta = a1.x; s.phi = a1.y;
+    s.pt = a2.x; s.pr = a2.y; s.ptheta = a3.x; s.pphi = a3.y;
+    s.k = a4.x; s.h = a4.y;
+    s.Q = p->Q;
+    const int2* iv = reinterpret_cast<const int2*>(&p->steps);
+    const int2 i0 = iv[0], i1 = iv[1], i2 = iv[2];
+    s.steps0 = i0.x; s.status = i0.y; s.rdot_sign = i1.x; s.thetadot_sign = i1.y; s.rdot_flips = i2.x; s.eq_cross = i2.y;
+}
+
+KR_DEV void store_ray(kr_ray_f64* p, const Lane<double>& s, int32_t out_steps)
+{
+    double2* d = reinterpret_cast<double2*>(p);
+    d[0] = make_double2(s.t, s.r);
+    d[1] = make_double2(s.theta, s.phi);
+    d[2] = make_double2(s.pt, s.pr);
+    d[3] = make_double2(s.ptheta, s.pphi);
+    int2* iv = reinterpret_cast<int2*>(&p->steps);
+    iv[0] = make_int2(out_steps, s.status);
+    iv[1] = make_int2(s.rdot_sign, s.thetadot_sign);
+    iv[2] = make_int2(s.rdot_flips, s.eq_cross);
+}
+
+KR_DEV void load_ray(const kr_ray_f32* p, Lane<float>& s)
+{
+    s.t = p->t; s.r = p->r; s.theta = p->theta; s.phi = p->phi;
+    s.pt = p->pt; s.pr = p->pr; s.ptheta = p->ptheta; s.pphi = p->pphi;
+    s.k = p->k; s.h = p->h; s.Q = p->Q;
+    s.steps0 = p->steps; s.status = p->status; s.rdot_sign = p->rdot_sign; s.thetadot_sign = p->thetadot_sign;
+    s.rdot_flips = p->rdot_flips; s.eq_cross = p->equatorial_crossings;
+}
+
+KR_DEV void store_ray(kr_ray_f32* p, const Lane<float>& s, int32_t out_steps)
+{
+    p->t = s.t; p->r = s.r; p->theta = s.theta; p->phi = s.phi;
+    p->pt = s.pt; p->pr = s.pr; p->ptheta = s.ptheta; p->pphi = s.pphi;
+    p->steps = out_steps; p->status = s.status; p->rdot_sign = s.rdot_sign; p->thetadot_sign = s.thetadot_sign;
+    p->rdot_flips = s.rdot_flips; p->equatorial_crossings = s.eq_cross;
+}
+
+template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---- the persistent kernel ------------------------------------------------------------------------
+// METHOD: KR_EULER / KR_RK4 / KR_RK45.  REFILL_MIN: a wave goes back to the queue when at least this many of its
+// lanes are free (or when none holds a ray).
+template <typename T, int METHOD, bool USE_DEST, int REFILL_MIN>
+__global__ void __launch_bounds__(kBlock)
+trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_bit = 1ull << lane;
+
+    Lane<T> s;
+    long long idx = -1;
+    bool have = false;          // this lane holds a ray
+    bool exhausted = false;     // wave-uniform: the queue head has passed n
+    unsigned long long my_steps = 0, my_traced = 0;
+    uint32_t my_attempts = 0, my_rejects = 0;
+
+    for (;;) {
+        const unsigned long long need = __ballot(!have);
+        const int n_need = __popcll(need);
+        const bool any_have = (need != ~0ull);
+
+        if (!exhausted && n_need > 0 && (n_need >= REFILL_MIN || !any_have)) {
+            // wave-aggregated dequeue: one atomic for all free lanes
+            const int leader = __ffsll((long long) need) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&counters[0], (unsigned long long) n_need);
+            base = __shfl(base, leader, 64);
+            if (base + (unsigned long long) n_need >= (unsigned long long) n) exhausted = true;
+            if (!have) {
+                const long long mine = (long long) base + __popcll(need & (lane_bit - 1));
+                if (mine < n) {
+                    load_ray(&rays[mine], s);
+                    // skip rule of run_raytrace (raytracer.cpp:116-117)
+                    if (s.steps0 >= 0 && s.steps0 < c.steplim) {
+                        idx = mine;
+                        have = true;
+                        ++my_traced;
+                        s.steps = 0;
+                        s.r_was_positive = false;
+                        s.theta_was_positive = true;
+                        s.in_retry = false;
+                        if (METHOD == KR_RK45) rk45_seed(s, c);
+                        if (!loop_cond<T, USE_DEST>(s, c)) {
+                            // zero-iteration call: only the epilogue runs
+                            const int32_t out_steps = finish_status<T, USE_DEST>(s, c);
+                            store_ray(&rays[idx], s, out_steps);
+                            have = false;
+                        }
+                    }
+                }
+            }
+            continue;   // re-evaluate the ballots (skipped / zero-iteration rays leave lanes free)
+        }
+
+        if (!any_have) break;   // nothing held and (exhausted or nothing needed): only reachable when exhausted
+
+        if (have) {
+            bool fin;
+            if (METHOD == KR_EULER) fin = step_fixed<T, false, USE_DEST>(s, c);
+            else if (METHOD == KR_RK4) fin = step_fixed<T, true, USE_DEST>(s, c);
+            else fin = step_rk45<T, USE_DEST>(s, c, my_attempts, my_rejects);
+            if (fin) {
+                my_steps += (unsigned long long) s.steps;
+                const int32_t out_steps = finish_status<T, USE_DEST>(s, c);
+                store_ray(&rays[idx], s, out_steps);
+                have = false;
+            }
+        }
+    }
+
+    // per-wave totals -> global counters (4 atomics per wave, once)
+    const unsigned long long w_traced = wave_sum<T>(my_traced);
+    const unsigned long long w_steps = wave_sum<T>(my_steps);
+    const unsigned long long w_att = wave_sum<T>((unsigned long long) my_attempts);
+    const unsigned long long w_rej = wave_sum<T>((unsigned long long) my_rejects);
+    if (lane == 0) {
+        if (w_traced) atomicAdd(&counters[1], w_traced);
+        if (w_steps) atomicAdd(&counters[2], w_steps);
+        if (w_att) atomicAdd(&counters[3], w_att);
+        if (w_rej) atomicAdd(&counters[4], w_rej);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+struct DeviceScratch {
+    unsigned long long* counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cus = 0;
+};
+std::mutex g_mu;
+DeviceScratch g_scratch[64];
+
+int scratch_for_current(DeviceScratch** out)
+{
+    int dev = 0;
+    KR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("device ordinal out of range"); return KR_EINVAL; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceScratch& sc = g_scratch[dev];
+    if (!sc.counters) {
+        KR_HIP(hipMalloc((void**) &sc.counters, kCounters * sizeof(unsigned long long)));
+        KR_HIP(hipEventCreate(&sc.ev0));
+        KR_HIP(hipEventCreate(&sc.ev1));
+        hipDeviceProp_t prop;
+        KR_HIP(hipGetDeviceProperties(&prop, dev));
+        sc.cus = prop.multiProcessorCount;
+    }
+    *out = &sc;
+    return KR_OK;
+}
+
+template <typename T>
+TraceConsts<T> make_consts(const kr_params* p, int steplim)
+{
+    TraceConsts<T> c;
+    c.a = (T) p->spin; c.horizon = (T) p->horizon; c.rlim = (T) p->r_max; c.thetalim = (T) p->theta_max;
+    c.precision = (T) p->precision; c.theta_precision = (T) p->theta_precision;
+    c.max_tstep = (T) p->max_tstep; c.maxtstep_rlim = (T) p->maxtstep_rlim; c.max_phistep = (T) p->max_phistep;
+    c.tol = (T) p->rk45_tol;
+    c.sp0 = (T) p->stop_params[0]; c.sp1 = (T) p->stop_params[1]; c.sp2 = (T) p->stop_params[2];
+    c.steplim = steplim;
+    c.stop_kind = p->stop_kind;
+    return c;
+}
+
+template <typename T, int METHOD, bool USE_DEST>
+int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, unsigned long long* counters, int cus,
+           hipStream_t stream)
+{
+    constexpr int kRefill = 1;
+    auto kern = trace_kernel<T, METHOD, USE_DEST, kRefill>;
+    int blocks_per_cu = 0;
+    KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, kBlock, 0));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    const int64_t resident = (int64_t) cus * blocks_per_cu;
+    const int64_t wanted = (n + kBlock - 1) / kBlock;
+    const int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, rays, (long long) n, c, counters);
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
+template <typename T>
+int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned long long* counters, int cus, hipStream_t stream)
+{
+    using R = typename RayOf<T>::type;
+    R* rays = (R*) d_rays;
+    const TraceConsts<T> c = make_consts<T>(p, steplim);
+    const bool dest = (p->stop_kind != KR_STOP_THETA);
+    switch (p->integrator) {
+        case KR_EULER: return launch<T, KR_EULER, false>(rays, n, c, counters, cus, stream);
+        case KR_RK4:
+            return dest ? launch<T, KR_RK4, true>(rays, n, c, counters, cus, stream)
+                        : launch<T, KR_RK4, false>(rays, n, c, counters, cus, stream);
+        default:
+            return dest ? launch<T, KR_RK45, true>(rays, n, c, counters, cus, stream)
+                        : launch<T, KR_RK45, false>(rays, n, c, counters, cus, stream);
+    }
+}
+
+}  // namespace
+
+int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, kr_stats* stats, bool f32)
+{
+    if (!p || (n > 0 && !d_rays) || n < 0) { set_error("kr_trace: null argument or negative n"); return KR_EINVAL; }
+    if (p->integrator < KR_EULER || p->integrator > KR_RK45) { set_error("kr_trace: unknown integrator"); return KR_EINVAL; }
+    if (p->stop_kind < KR_STOP_THETA || p->stop_kind > KR_STOP_FLATPLANE) { set_error("kr_trace: unknown stop_kind"); return KR_EINVAL; }
+    if (p->stop_kind != KR_STOP_THETA && p->integrator == KR_EULER) {
+        // assert(method != Integrator::Euler), raytracer.cpp:983
+        set_error("kr_trace: Integrator::Euler does not support RayDestination stopping conditions");
+        return KR_EINVAL;
+    }
+    int rc = require_device();
+    if (rc != KR_OK) return rc;
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->rays_total = n; }
+    if (n == 0) return KR_OK;
+
+    // effective_steplim, raytracer.cpp:80
+    const int steplim = (p->steplim > 0) ? p->steplim : (p->integrator == KR_RK45) ? KR_RK45_STEPLIM : KR_STEPLIM;
+
+    DeviceScratch* sc = nullptr;
+    rc = scratch_for_current(&sc);
+    if (rc != KR_OK) return rc;
+
+    KR_HIP(hipMemsetAsync(sc->counters, 0, kCounters * sizeof(unsigned long long), stream));
+    if (stats) KR_HIP(hipEventRecord(sc->ev0, stream));
+    rc = f32 ? dispatch<float>(p, d_rays, n, steplim, sc->counters, sc->cus, stream)
+             : dispatch<double>(p, d_rays, n, steplim, sc->counters, sc->cus, stream);
+    if (rc != KR_OK) return rc;
+    if (stats) {
+        KR_HIP(hipEventRecord(sc->ev1, stream));
+        unsigned long long h[kCounters];
+        KR_HIP(hipMemcpyAsync(h, sc->counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+        KR_HIP(hipStreamSynchronize(stream));
+        float ms = 0;
+        KR_HIP(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
+        stats->rays_traced = (int64_t) h[1];
+        stats->steps_total = (int64_t) h[2];
+        stats->rk45_attempts = (int64_t) h[3];
+        stats->rk45_rejects = (int64_t) h[4];
+        stats->kernel_ms = ms;
+    }
+    return KR_OK;
+}
+
+}  // namespace kr

@@ -1,0 +1,251 @@
+"""GPU: the HIP path, called through the C ABI, against (a) the committed golden fixtures captured from the
+compiled reference and (b) the oracle on the same seeded inputs.  Tolerances: tests/parity.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+import oracle_lib as ol
+import parity
+from raytrace_cpu_amd import api, capi
+
+pytestmark = pytest.mark.gpu
+
+CASES = gc.cases()
+RUNS = [(c, r) for c in CASES for r in CASES[c]["runs"]]
+
+
+def hip_pipeline(case, params, init):
+    """run_raytrace -> range_phi -> redshift through libkrtrace, starting from the reference's own init rays."""
+    out, st = api.trace(params, init)
+    api.range_phi(out)
+    V, rev, proj = case["post"]
+    if params.stop_kind == capi.STOP_THETA:
+        api.redshift(params.spin, V, rev, proj, out)
+    else:
+        api.redshift_dest(params.spin, rev, out)
+    return out, st
+
+
+@pytest.mark.parametrize("case_name,run", RUNS)
+def test_trace_vs_golden(krlib, case_name, run):
+    case = CASES[case_name]
+    g = np.load(gc.golden_path(case_name))
+    params = case["runs"][run]
+    out, st = hip_pipeline(case, params, g["init"])
+    want = g[f"final__{run}"]
+    rtol = parity.rtol_for(params)
+    res = parity.compare_rays(out, want, rtol=rtol, check_redshift=True)
+    assert res["n_traced"] > 0
+    assert res["frac_bad"] <= parity.allowed_bad_frac(params, g["init"], rtol), res
+    # the kernel's own step counter agrees with the per-ray records it wrote
+    live = out["steps"] != -1
+    assert st["steps_total"] == int((np.abs(out["steps"][live].astype(np.int64)) - np.abs(g["init"]["steps"][live].astype(np.int64))).sum())
+    assert abs(st["steps_total"] - int(g[f"steps__{run}"])) <= 0.01 * int(g[f"steps__{run}"]) + 2 * res["n_traced"]
+    assert st["rays_traced"] == int((g["init"]["steps"] >= 0).sum())
+
+
+@pytest.mark.parametrize("case_name", ["ps_h5", "ps_h10", "ps_kep"])
+@pytest.mark.parametrize("run", ["euler", "rk4", "rk45"])
+def test_emissivity_bins_vs_golden(krlib, case_name, run):
+    case = CASES[case_name]
+    if run not in case["runs"]:
+        pytest.skip("run not defined for this case")
+    g = np.load(gc.golden_path(case_name))
+    out, _ = hip_pipeline(case, case["runs"][run], g["init"])
+    bins = gc.emis_bins(case["source"])
+    got = api.reduce_emissivity(bins, out)
+    # the oracle's reducer on the REFERENCE's final rays
+    want = oracle_reduce_emissivity(bins, g[f"final__{run}"])
+    assert want["disc_count"] > 0
+    assert parity.compare_bins(got, want) == []
+    assert abs(got["disc_count"] - want["disc_count"]) <= parity.BIN_COUNT_SLACK
+
+
+def oracle_reduce_emissivity(bins, rays):
+    nr = bins.nr
+    count = np.zeros(nr, dtype=np.int64)
+    flux, emis, sg, stt = (np.zeros(nr) for _ in range(4))
+    dc = C.c_int64()
+    ol.oracle().kro_reduce_emissivity_f64(C.byref(bins), ol.ptr(rays), len(rays), ol.ptr(count), ol.ptr(flux), ol.ptr(emis),
+                                          ol.ptr(sg), ol.ptr(stt), C.byref(dc))
+    return {"count": count, "flux": flux, "emis": emis, "sum_redshift": sg, "sum_time": stt, "disc_count": dc.value}
+
+
+def oracle_reduce_image(bins, rays):
+    npix = bins.img_nx * bins.img_ny
+    nrays = np.zeros(npix, dtype=np.int32)
+    keys = ("flux", "r", "phi", "enshift", "time", "emis")
+    planes = {k: np.zeros(npix) for k in keys}
+    dc = C.c_int64()
+    ol.oracle().kro_reduce_image_f64(C.byref(bins), ol.ptr(rays), len(rays), ol.ptr(nrays), *[ol.ptr(planes[k]) for k in keys], C.byref(dc))
+    out = {"nrays": nrays, "disc_count": dc.value}
+    out.update(planes)
+    return out
+
+
+@pytest.mark.parametrize("case_name,run", [("ip15", "rk4"), ("ip15", "rk45"), ("ip16", "rk4")])
+def test_image_planes_vs_golden(krlib, case_name, run):
+    case = CASES[case_name]
+    g = np.load(gc.golden_path(case_name))
+    out, _ = hip_pipeline(case, case["runs"][run], g["init"])
+    bins = gc.image_bins(case["source"])
+    got = api.reduce_image(bins, out)
+    want = oracle_reduce_image(bins, g[f"final__{run}"])
+    assert want["disc_count"] > 0
+    assert np.abs(got["nrays"].astype(int) - want["nrays"].astype(int)).max() <= parity.BIN_COUNT_SLACK
+    same = got["nrays"] == want["nrays"]
+    for k in ("flux", "r", "phi", "enshift", "time", "emis"):
+        np.testing.assert_allclose(got[k][same], want[k][same], rtol=parity.BIN_RTOL, atol=1e-12, err_msg=k)
+
+
+# ---- sources and O(N) passes against the oracle ---------------------------------------------------------------
+@pytest.mark.parametrize("case_name", list(CASES))
+def test_source_init_and_redshift_start(krlib, case_name):
+    case = CASES[case_name]
+    spec = case["source"]
+    g = np.load(gc.golden_path(case_name))
+    rays = api.imageplane_init(spec) if gc.is_imageplane(case) else api.pointsource_init(spec)
+    assert len(rays) == len(g["init"])
+    params = next(iter(case["runs"].values()))
+    V, rev, proj = case["start"]
+    api.redshift_start(params.spin, V, rev, proj, rays)
+    want = g["init"]
+    assert (rays["steps"] == want["steps"]).all()
+    live = want["steps"] == 0
+    for f in ("rdot_sign", "thetadot_sign", "rdot_flips", "equatorial_crossings", "status"):
+        assert (rays[f][live] == want[f][live]).all(), f
+    for f in ("t", "r", "theta", "phi", "pt", "pr", "ptheta", "pphi", "k", "h", "Q", "emit", "alpha", "beta"):
+        ok = live & ~(np.isnan(want[f]))
+        np.testing.assert_allclose(rays[f][ok], want[f][ok], rtol=1e-11, atol=1e-13, err_msg=f)
+        assert np.isnan(rays[f][live & np.isnan(want[f])]).all(), f
+
+
+def test_redshift_variants_vs_oracle(krlib):
+    g = np.load(gc.golden_path("ps_h5"))
+    fin = g["final__rk4"]
+    o = ol.oracle()
+    for (V, rev, proj, motion) in [(-1.0, 0, 0, 0), (-1.0, 0, 1, 0), (0.05, 0, 0, 0), (-0.3, 0, 0, 1), (-1.0, 1, 0, 0)]:
+        a, b = fin.copy(), fin.copy()
+        api.redshift(gc.SPIN, V, rev, proj, a, motion=motion)
+        o.kro_redshift_f64(gc.SPIN, V, rev, proj, motion, ol.ptr(b), len(b))
+        live = (fin["steps"] > 0) & np.isfinite(b["redshift"])
+        np.testing.assert_allclose(a["redshift"][live], b["redshift"][live], rtol=1e-10)
+    a, b = fin.copy(), fin.copy()
+    api.calculate_momentum(gc.SPIN, a)
+    o.kro_calculate_momentum_f64(gc.SPIN, ol.ptr(b), len(b))
+    live = fin["steps"] > 0
+    for f in ("pt", "pr", "ptheta", "pphi"):
+        np.testing.assert_allclose(a[f][live], b[f][live], rtol=1e-10, atol=1e-14)
+    # redshift_start with V = -1: the first record's orbital velocity is reused for every ray (raytracer.cpp:391-394)
+    a, b = g["init"].copy(), g["init"].copy()
+    api.redshift_start(gc.SPIN, -1.0, 0, 0, a)
+    o.kro_redshift_start_f64(gc.SPIN, -1.0, 0, 0, ol.ptr(b), len(b))
+    live = g["init"]["steps"] == 0
+    np.testing.assert_allclose(a["emit"][live], b["emit"][live], rtol=1e-10)
+
+
+def test_range_phi_bitwise(krlib):
+    rays = np.zeros(4096, dtype=capi.RAY_F64)
+    rng = np.random.default_rng(7)
+    rays["phi"] = rng.uniform(-1200, 1200, len(rays))
+    rays["phi"][:8] = [np.nan, np.pi, -np.pi, 1000.0, -1000.0, 999.9999, 0.0, 3 * np.pi]
+    rays["steps"] = rng.integers(-2, 3, len(rays))
+    a, b = rays.copy(), rays.copy()
+    api.range_phi(a)
+    ol.oracle().kro_range_phi_f64(-np.pi, np.pi, ol.ptr(b), len(b))
+    assert ol.rays_equal_bitwise(a, b) == []
+
+
+# ---- edge cases ------------------------------------------------------------------------------------------------
+def test_empty_and_skipped_inputs(krlib):
+    p = capi.default_params(gc.SPIN)
+    p.integrator = capi.RK4
+    empty = np.zeros(0, dtype=capi.RAY_F64)
+    out, st = api.trace(p, empty)
+    assert len(out) == 0 and st["rays_traced"] == 0
+    # all rays invalid (steps = -1) or already at the step limit: nothing may change
+    rays = np.zeros(1000, dtype=capi.RAY_F64)
+    rays["steps"] = -1
+    rays["steps"][::3] = 10_000_000
+    rays["r"] = 5.0
+    out, st = api.trace(p, rays)
+    assert st["rays_traced"] == 0 and st["steps_total"] == 0
+    assert ol.rays_equal_bitwise(out, rays) == []
+
+
+def test_ragged_sizes_match_oracle(krlib):
+    """n not a multiple of the wave / workgroup size, down to a single ray."""
+    g = np.load(gc.golden_path("ps_h10"))
+    init = g["init"]
+    p = CASES["ps_h10"]["runs"]["rk4"]
+    for n in (1, 63, 64, 65, 257, 1001):
+        sub = init[200:200 + n].copy()
+        out, _ = api.trace(p, sub)
+        want, _ = ol.oracle_trace(p, sub)
+        res = parity.compare_rays(out, want)
+        assert res["n_bad"] <= max(1, int(0.02 * n)), (n, res)
+
+
+def test_rerun_is_idempotent_and_resumes(krlib):
+    """run_raytrace re-entrancy (raytracer.cpp:116-117, :335-337)."""
+    g = np.load(gc.golden_path("ps_h5"))
+    p = capi.copy_params(CASES["ps_h5"]["runs"]["rk4"], steplim=300)
+    out1, st1 = api.trace(p, g["init"])
+    lim = (out1["status"] & capi.STATUS_STEPLIM) != 0
+    assert lim.any() and (out1["steps"][lim] == -300).all()
+    out2, st2 = api.trace(p, out1)
+    assert st2["steps_total"] == 0
+    assert ol.rays_equal_bitwise(out1, out2) == []
+
+
+def test_invalid_arguments_fail_loudly(krlib):
+    p = capi.default_params(0.5)
+    rays = np.zeros(4, dtype=capi.RAY_F64)
+    p.integrator, p.stop_kind = capi.EULER, capi.STOP_FLATDISC          # assert in raytracer.cpp:983
+    assert krlib.kr_trace_f64(C.byref(p), ol.ptr(rays), 4, None) == capi.KR_EINVAL
+    assert b"Euler" in krlib.kr_last_error()
+    p.integrator, p.stop_kind = 9, capi.STOP_THETA
+    assert krlib.kr_trace_f64(C.byref(p), ol.ptr(rays), 4, None) == capi.KR_EINVAL
+    p.integrator = capi.RK4
+    assert krlib.kr_trace_f64(C.byref(p), None, 4, None) == capi.KR_EINVAL
+
+
+def test_nan_ray_terminates(krlib):
+    """ImagePlane pixel (0,0) has NaN constants; the reference's RK45 never returns for it.
+    The device path must end the ray (KR_STATUS_NAN) and leave the others untouched by it."""
+    g = np.load(gc.golden_path("ip16"))
+    init = g["init"]
+    nan_rays = np.flatnonzero(np.isnan(init["h"]) & (init["steps"] == 0))
+    assert len(nan_rays) == 1
+    p = capi.copy_params(CASES["ip16"]["runs"]["rk4"], integrator=capi.RK45)
+    out, _ = api.trace(p, init)
+    i = nan_rays[0]
+    assert out["status"][i] & capi.STATUS_NAN
+    want, _ = ol.oracle_trace(p, init)        # the oracle mirrors the same documented deviation
+    res = parity.compare_rays(out, want, rtol=parity.rtol_for(p))
+    assert res["frac_bad"] <= parity.CHAOTIC_FRAC, res
+
+
+# ---- larger grids against the oracle run on the spot --------------------------------------------------------------
+@pytest.mark.parametrize("method", [capi.EULER, capi.RK4, capi.RK45])
+def test_perf_test_grid_vs_oracle(krlib, method):
+    """integrator_perf_test.cpp:35-45 grid (5167 rays) at BASELINE's h = 10: per-ray and per-bin parity."""
+    spec = ol.pointsource_spec([0.0, 10.0, 1e-3, 1.5707], 0.0, gc.SPIN, 0.05, 0.05, cosalpha0=-0.995, cosalphamax=0.995,
+                               beta0=-np.pi, betamax=np.pi)
+    init = ol.oracle_pointsource(spec)
+    ol.oracle().kro_redshift_start_f64(gc.SPIN, 0.0, 0, 0, ol.ptr(init), len(init))
+    p = capi.default_params(gc.SPIN)
+    p.integrator = method
+    want, wst = ol.oracle_trace(p, init)
+    ol.oracle().kro_range_phi_f64(-np.pi, np.pi, ol.ptr(want), len(want))
+    ol.oracle().kro_redshift_f64(gc.SPIN, -1.0, 0, 0, 0, ol.ptr(want), len(want))
+    out, st = api.trace(p, init)
+    api.range_phi(out)
+    api.redshift(gc.SPIN, -1.0, 0, 0, out)
+    res = parity.compare_rays(out, want, rtol=parity.rtol_for(p), check_redshift=True)
+    assert res["frac_bad"] <= parity.CHAOTIC_FRAC, res
+    bins = gc.emis_bins(spec, nr=30)
+    assert parity.compare_bins(api.reduce_emissivity(bins, out), oracle_reduce_emissivity(bins, want)) == []
+    assert abs(st["steps_total"] - wst["steps_total"]) <= 0.01 * wst["steps_total"]
