@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: rays/s (and RK steps/s) to disc hit, PointSource emissivity a = 0.998.
+
+One "step" = one pass of the hot path over one batch of synthetic rays, entirely in HBM:
+    PointSource init -> redshift_start -> run_raytrace (RK4, theta_max = pi/2, r_max = 1000)
+    -> range_phi -> redshift -> emissivity histogram  [-> RCCL all-reduce of the histogram when N > 1]
+Workload at N = 1: BASELINE.json configs[1] -- par_example/emissivity.par_example source with --source_h=10
+(source = 0 10 1E-3 1.5707, V = 0, spin = 0.998), cos(alpha) in [-0.995, 0.995), beta in [-pi, pi), a
+3163 x 3163 grid ~ 1e7 rays, fixed-step RK4, fp64.  For N > 1 the grid is refined N-fold in cos(alpha) and
+rank r owns rows r, r+N, r+2N, ... (row-cyclic: neighbouring rows cost the same, so ranks stay balanced),
+i.e. per-GPU work is fixed (weak scaling); the only exchange is the all-reduce of the 5*Nr+1 histogram words.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--integrator rk4|rk45|euler]
+        (N > 1: launched by torch.distributed.run, one rank per GPU)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SPIN = 0.998
+SOURCE = [0.0, 10.0, 1e-3, 1.5707]
+R_MAX = 1000.0
+NR, R_DISC, GAMMA = 100, 500.0, 2.0             # emissivity.cpp defaults (Nr = 100, r_esc default 500 for r_disc, gamma = 2)
+FLOP_PER_STEP = {"euler": 100.0, "rk4": 340.0, "rk45": 590.0}   # algorithmic fp64 FLOP per step / per RK45 attempt
+FP64_VECTOR_PEAK_TFLOPS = 78.6                   # MI355X vector fp64: 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def make_spec(capi, d, rank=0, world=1, refine=1):
+    """PointSource spec.  Base grid: spacing d in cos(alpha) and d*pi/0.995 in beta (same point count on both axes).
+    world > 1: rank `rank` owns rows rank, rank+world, ... of the grid refined world-fold in cos(alpha).
+    refine > 1 (with world = 1): that whole refined grid, used for the flux normalisation."""
+    s = capi.PointSourceSpec()
+    for i in range(4):
+        s.pos[i] = SOURCE[i]
+    s.V, s.spin, s.tol, s.E = 0.0, SPIN, 100.0, 1.0
+    s.cosalpha0, s.cosalphamax, s.dcosalpha = -0.995 + rank * (d / world), 0.995, d / refine
+    s.beta0, s.betamax, s.dbeta = -math.pi, math.pi, d * math.pi / 0.995
+    return s
+
+
+def grid_spacing_for(rays):
+    return 1.99 / (math.sqrt(rays) - 1.0)
+
+
+def emis_bins(capi, kerr_isco, n_primary):
+    b = capi.EmisBins()
+    b.r_isco = kerr_isco
+    b.r_min = kerr_isco
+    b.dr = math.exp(math.log(R_DISC / b.r_min) / NR)
+    b.gamma, b.spin, b.num_primary_rays = GAMMA, SPIN, float(n_primary)
+    b.nr, b.logbin = NR, 1
+    return b
+
+
+def cpu_baseline(args, capi, api, integrator, d_full):
+    """Times the CPU path on a bounded sample of the same workload (same source, same angular ranges, coarser
+    grid), on this box's host cores, and checks the GPU histogram of that same sample against it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol   # bench.py's cpu_baseline leg is one of the three places allowed to touch oracle/
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    # ~ 2.5e4 rays per core: 10-30 s of CPU work at ~5e6 RK4 steps/s/core and ~550 steps/ray
+    sample_rays = int(args.cpu_sample_rays or 25000 * cores)
+    d = grid_spacing_for(sample_rays)
+    spec = make_spec(capi, d)
+    p = capi.default_params(SPIN)
+    p.integrator, p.r_max = integrator, R_MAX
+    kind = "reference" if ol.ref() is not None else "port"
+    if kind == "reference":
+        src = ol.RefSource(spec)                       # the reference's own PointSource<double>
+        src.lib.ref_redshift_start(src.h, 0.0, 0, 0)
+        init = src.snapshot()
+        t0 = time.perf_counter()
+        src.run(p)                                     # Raytracer::run_raytrace, OpenMP over all host cores
+        wall = time.perf_counter() - t0
+        cpu_rays = src.snapshot()
+        src.close()
+    else:
+        init = ol.oracle_pointsource(spec)
+        ol.oracle().kro_redshift_start_f64(SPIN, 0.0, 0, 0, ol.ptr(init), len(init))
+        t0 = time.perf_counter()
+        cpu_rays, _ = ol.oracle_trace(p, init, nthreads=cores)
+        wall = time.perf_counter() - t0
+    valid = cpu_rays["steps"] != -1
+    n_valid = int(valid.sum())
+    steps = int(np.abs(cpu_rays["steps"][valid].astype(np.int64)).sum())
+    # parity of the emissivity bins on this sample: GPU (same init rays, through the C ABI) vs CPU
+    o = ol.oracle()
+    o.kro_range_phi_f64(-math.pi, math.pi, ol.ptr(cpu_rays), len(cpu_rays))
+    o.kro_redshift_f64(SPIN, -1.0, 0, 0, 0, ol.ptr(cpu_rays), len(cpu_rays))
+    n_primary = int(((spec.cosalphamax - spec.cosalpha0) / spec.dcosalpha) * ((spec.betamax - spec.beta0) / spec.dbeta))
+    bins = emis_bins(capi, api.lib().kr_kerr_isco(SPIN, 1), n_primary)
+    gpu_rays, _ = api.trace(p, init)
+    api.range_phi(gpu_rays)
+    api.redshift(SPIN, -1.0, 0, 0, gpu_rays)
+    got = api.reduce_emissivity(bins, gpu_rays)
+    nr = bins.nr
+    cnt = np.zeros(nr, dtype=np.int64)
+    flux, emis, sg, stt = (np.zeros(nr) for _ in range(4))
+    dc = C.c_int64()
+    o.kro_reduce_emissivity_f64(C.byref(bins), ol.ptr(cpu_rays), len(cpu_rays), ol.ptr(cnt), ol.ptr(flux), ol.ptr(emis), ol.ptr(sg), ol.ptr(stt), C.byref(dc))
+    same = cnt == got["count"]
+    worst = 0.0
+    for k, w in (("flux", flux), ("emis", emis), ("sum_redshift", sg), ("sum_time", stt)):
+        g = got[k][same & (cnt > 0)]
+        ww = w[same & (cnt > 0)]
+        if len(ww):
+            worst = max(worst, float(np.max(np.abs(g - ww) / np.abs(ww))))
+    unit = "rays/s"
+    return {
+        "value": n_valid / wall, "unit": unit, "cores": cores, "kind": kind,
+        "sample": f"same source and angular ranges on a {math.isqrt(len(init))}^2-ish grid: {n_valid} rays, {steps} steps, "
+                  f"run_raytrace only ({'reference sources, g++ -O2 -fopenmp -ffp-contract=off' if kind == 'reference' else 'oracle C port, gcc -O2 -fopenmp'})",
+        "steps_per_sec": steps / wall, "wall_s": wall,
+        "bins_check": {"bins": int(nr), "bins_count_mismatch": int((~same).sum()), "max_count_diff": int(np.abs(cnt - got["count"]).max()),
+                       "max_rel_diff_on_matching_bins": worst, "tolerance": 1e-6},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rays", type=float, default=1e7, help="rays per GPU (BASELINE configs[1]: 1e7)")
+    ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rays", type=float, default=0)
+    args = ap.parse_args()
+
+    import torch
+    from raytrace_cpu_amd import api, capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    lib = api.lib()
+    capi.check(lib, lib.kr_set_device(local_rank), "kr_set_device")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[args.integrator]
+    d = grid_spacing_for(args.rays)
+    spec = make_spec(capi, d, rank, world)
+    n, n_ca, n_b = api.pointsource_count(spec)
+    full = make_spec(capi, d, refine=world)     # the global grid, for the flux normalisation
+    n_primary = int(((full.cosalphamax - full.cosalpha0) / full.dcosalpha) * ((full.betamax - full.beta0) / full.dbeta))
+    isco = lib.kr_kerr_isco(SPIN, 1)
+    bins = emis_bins(capi, isco, n_primary)
+    p = capi.default_params(SPIN)
+    p.integrator, p.r_max = method, R_MAX
+
+    rays = torch.empty(n * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda")
+    hist = torch.zeros(5 * NR + 1, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    d_rays, d_hist = rays.data_ptr(), hist.data_ptr()
+    vp = C.c_void_p
+
+    def one_step():
+        hist.zero_()
+        capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(spec), vp(d_rays), n, vp(stream)), "init")
+        capi.check(lib, lib.kr_redshift_start_dev_f64(SPIN, 0.0, 0, 0, vp(d_rays), n, vp(stream)), "redshift_start")
+        st = api.trace_dev(p, d_rays, n, stream=stream, want_stats=True)
+        capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(d_rays), n, vp(stream)), "range_phi")
+        capi.check(lib, lib.kr_redshift_dev_f64(SPIN, -1.0, 0, 0, 0, vp(d_rays), n, vp(stream)), "redshift")
+        capi.check(lib, lib.kr_reduce_emissivity_dev_f64(C.byref(bins), vp(d_rays), n, vp(d_hist), vp(stream)), "reduce")
+        if dist is not None:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM)      # RCCL over xGMI: the path's one exchange
+        return st
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms, steps_total, traced = [], 0, 0
+    for _ in range(args.steps):
+        st = one_step()
+        kernel_ms.append(st["kernel_ms"])
+        steps_total, traced = st["steps_total"], st["rays_traced"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([float(traced), float(steps_total)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        traced_all, steps_all = int(tot[0].item()), int(tot[1].item())
+    else:
+        traced_all, steps_all = traced, steps_total
+
+    h = hist.cpu().numpy()
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        flop = FLOP_PER_STEP[args.integrator] * steps_total          # this rank's launch
+        achieved_tflops = flop / (avg_kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "trace_kernel_hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.integrator)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "rays_per_sec", "value": traced_all * args.steps / elapsed, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"PointSource emissivity lamp-post h=10 a=0.998 V=0, {args.integrator.upper()} fixed tol, theta_max=pi/2 r_max=1000 "
+                                   f"(BASELINE configs[1]); grid {n_ca}x{n_b} per GPU", "rays_per_gpu": int(traced),
+                       "allocated_rays_per_gpu": int(n), "rays_total": int(traced_all), "integrator": args.integrator,
+                       "pipeline": "init+redshift_start+trace+range_phi+redshift+histogram" + ("+rccl_allreduce" if world > 1 else ""),
+                       "sharding": f"row-cyclic over {world} rank(s)"},
+            "rk_steps_per_sec": steps_all * args.steps / elapsed,
+            "rk_steps_per_launch": int(steps_total), "mean_steps_per_ray": steps_total / max(traced, 1),
+            "disc_hits": float(h[5 * NR]),
+            "roofline": {"bound": "valu_fp64", "kernel": "kr::trace_kernel<double>", "achieved": achieved_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
+                         "flop_per_step": FLOP_PER_STEP[args.integrator], "avg_kernel_ms": avg_kernel_ms,
+                         "kernel_steps_per_sec": steps_total / (avg_kernel_ms * 1e-3),
+                         "hbm": {"algorithmic_bytes": 288 * int(traced), "achieved_gbs": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9,
+                                 "peak_gbs": HBM_PEAK_GBS, "frac": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "traffic": traffic,
+                         "note": "latency-bound scalar fp64 ODE: neither HBM nor MFMA bounds it (SURVEY.md 8d); priced against vector fp64 peak"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, capi, api, method, d)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,9 @@ int         kr_device_count(void);                 /* <0: KR_ENODEVICE */
 int         kr_set_device(int device);
 int         kr_device_info(int* cu_count, int* clock_khz, int64_t* hbm_bytes, char* name, int name_len);
 void        kr_params_default(kr_params* p, double spin);   /* Raytracer ctor defaults, raytracer.cpp:12-22 */
+double      kr_kerr_horizon(double a);                      /* kerr_horizon(), src/include/kerr.h:14-20 */
+double      kr_kerr_isco(double a, int sign);               /* kerr_isco(), kerr.h:23-32 (float-rounded A, B: sic) */
+double      kr_disc_velocity(double r, double a, int sign); /* disc_velocity(), kerr.h:35-38 */
 int64_t     kr_pointsource_count(const kr_pointsource* s, int32_t* n_cosalpha, int32_t* n_beta);   /* pointsource.cpp:12,16-17 */
 int64_t     kr_imageplane_count(const kr_imageplane* s, int32_t* nx, int32_t* ny);                 /* imageplane.cpp:12-14 */
 

@@ -98,6 +98,9 @@ PROTOTYPES = {
     "kr_set_device": (_int, [_int]),
     "kr_device_info": (_int, [P(_int), P(_int), P(_i64), C.c_char_p, _int]),
     "kr_params_default": (None, [P(Params), _dbl]),
+    "kr_kerr_horizon": (_dbl, [_dbl]),
+    "kr_kerr_isco": (_dbl, [_dbl, _int]),
+    "kr_disc_velocity": (_dbl, [_dbl, _dbl, _int]),
     "kr_pointsource_count": (_i64, [P(PointSourceSpec), P(_i32), P(_i32)]),
     "kr_imageplane_count": (_i64, [P(ImagePlaneSpec), P(_i32), P(_i32)]),
     "kr_trace_f64": (_int, [P(Params), _vp, _i64, P(Stats)]),

@@ -149,6 +149,25 @@ void kr_params_default(kr_params* p, double spin)
     p->steplim = -1;
 }
 
+// src/include/kerr.h:14-20
+double kr_kerr_horizon(double a) { return 1 + std::sqrt((1 - a) * (1 + a)); }
+
+// src/include/kerr.h:23-32: A and B are `const float`, and with `using namespace std` in force the last sqrt
+// is the float overload, so the ISCO radius the apps bin against is a float-precision number
+// (r_isco(0.998) = 1.2369706630706787).  Reproduced, not fixed: it is a bin edge.
+double kr_kerr_isco(double a, int sign)
+{
+    const float A = (float) (1. + std::pow(1. - a * a, 1. / 3.) * (std::pow(1. + a, 1. / 3.) + std::pow(1. - a, 1. / 3.)));
+    const float AA = A * A;
+    const float B = (float) std::sqrt(3. * a * a + AA);
+    const float inner = (3 - A) * (3 + A + 2 * B);
+    const float res = 3 + B - sign * std::sqrt(inner);
+    return res;
+}
+
+// src/include/kerr.h:35-38
+double kr_disc_velocity(double r, double a, int sign) { return 1 / (a + sign * std::pow(r, 3. / 2.)); }
+
 // nRays is the int-truncated PRODUCT of doubles (pointsource.cpp:12), n_cosalpha / n_beta the truncated factors (:16-17)
 int64_t kr_pointsource_count(const kr_pointsource* s, int32_t* n_cosalpha, int32_t* n_beta)
 {
