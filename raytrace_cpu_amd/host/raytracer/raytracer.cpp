@@ -1,0 +1,405 @@
+// raytracer/raytracer.cpp -- Raytracer<T> members of the host-side API mirror.
+//
+// run_raytrace (both overloads; reference raytracer.cpp:63-127, :972-1034) and, for T = double, the O(N)
+// passes (redshift_start :342-417, redshift :420-477, range_phi :603-622, calculate_momentum :704-753) are
+// calls into libkrtrace.so (include/kr_trace.h) and execute on the GPU.  The float instantiation
+// (reference raytracer.cpp:1897) traces on the GPU as well (kr_trace_f32); its O(N) passes, the per-ray
+// ray_redshift() helpers and redshift() with a user-defined velocity field are plain host loops, as they
+// are in the reference, because they call back into virtual / per-ray host code.
+
+#include "raytracer.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <typeinfo>
+
+#include "../../../include/kr_trace.h"
+#include "ray_destination.h"
+
+static_assert(sizeof(Ray<double>) == sizeof(kr_ray_f64), "Ray<double> must be layout-identical to kr_ray_f64");
+static_assert(sizeof(Ray<float>) == sizeof(kr_ray_f32), "Ray<float> must be layout-identical to kr_ray_f32");
+
+namespace {
+
+[[noreturn]] void fail(const char* what, int rc)
+{
+    const char* msg = kr_last_error();
+    throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + (msg ? msg : ""));
+}
+
+inline void check(int rc, const char* what)
+{
+    if (rc != KR_OK) fail(what, rc);
+}
+
+int trace_call(const kr_params* p, Ray<double>* rays, long n) { return kr_trace_f64(p, reinterpret_cast<kr_ray_f64*>(rays), n, nullptr); }
+int trace_call(const kr_params* p, Ray<float>* rays, long n) { return kr_trace_f32(p, reinterpret_cast<kr_ray_f32*>(rays), n, nullptr); }
+
+template <typename T>
+bool builtin_destination(const RayDestination<T>* dest, int& kind, double sp[4], bool& default_velocity)
+{
+    if (!dest) return false;
+    const std::type_info& ti = typeid(*dest);
+    const bool exact = ti == typeid(FlatDiscDestination<T>) || ti == typeid(DiscWithISCODestination<T>) || ti == typeid(FlatPlaneDestination<T>);
+    return exact && dest->describe(kind, sp, default_velocity);
+}
+
+void no_outfile(const TextOutput* outfile)
+{
+    if (outfile != nullptr)
+        throw std::runtime_error("Raytracer: per-step trajectory output (outfile != nullptr) is not supported by the HIP path; "
+                                 "it is an ordered per-step file write that the reference runs serially on the CPU");
+}
+
+}  // namespace
+
+template <typename T>
+Raytracer<T>::Raytracer(int num_rays, T spin_par, T init_precision, T init_max_phistep, T init_max_tstep)
+    : precision(init_precision),
+      theta_precision(THETA_PRECISION),
+      max_tstep(init_max_tstep),
+      max_phistep(init_max_phistep),
+      maxtstep_rlim(MAXDT_RLIM),
+      rk45_tol(T(1e-8)),
+      nRays(num_rays),
+      spin(spin_par)
+{
+    horizon = kerr_horizon<T>(spin);
+    rays = new Ray<T>[nRays]();          // value-initialised
+    for (int ray = 0; ray < nRays; ray++) {
+        rays[ray].steps = -1;
+        rays[ray].status = 0;
+    }
+}
+
+template <typename T>
+Raytracer<T>::~Raytracer()
+{
+    delete[] rays;
+}
+
+template <typename T>
+void Raytracer<T>::fill_params(void* out, Integrator method, T r_max, int steplim) const
+{
+    kr_params* p = static_cast<kr_params*>(out);
+    std::memset(p, 0, sizeof(*p));
+    p->spin = spin;
+    p->horizon = horizon;
+    p->precision = precision;
+    p->theta_precision = theta_precision;
+    p->max_tstep = max_tstep;
+    p->maxtstep_rlim = maxtstep_rlim;
+    p->max_phistep = max_phistep;
+    p->rk45_tol = rk45_tol;
+    p->r_max = r_max;
+    p->theta_max = 0;
+    p->integrator = static_cast<int>(method);   // Euler, RK4, RK45 == KR_EULER, KR_RK4, KR_RK45
+    p->stop_kind = KR_STOP_THETA;
+    p->steplim = steplim;                        // <= 0 selects STEPLIM / RK45_STEPLIM inside the library
+}
+
+template <typename T>
+void Raytracer<T>::trace(const void* params, Ray<T>* first, long n)
+{
+    check(trace_call(static_cast<const kr_params*>(params), first, n), "kr_trace");
+}
+
+template <typename T>
+void Raytracer<T>::run_raytrace(Integrator method, T theta_max, T r_max, int show_progress, TextOutput* outfile, int write_step,
+                                T write_rmax, T write_rmin, bool write_cartesian, int steplim)
+{
+    (void) show_progress; (void) write_step; (void) write_rmax; (void) write_rmin; (void) write_cartesian;
+    no_outfile(outfile);
+    kr_params p;
+    fill_params(&p, method, r_max, steplim);
+    p.theta_max = theta_max;
+    trace(&p, rays, nRays);
+}
+
+template <typename T>
+void Raytracer<T>::run_raytrace(RayDestination<T>* dest, Integrator method, T r_max, int show_progress, TextOutput* outfile,
+                                int write_step, T write_rmax, T write_rmin, bool write_cartesian, int steplim)
+{
+    (void) show_progress; (void) write_step; (void) write_rmax; (void) write_rmin; (void) write_cartesian;
+    no_outfile(outfile);
+    if (method == Integrator::Euler)   // assert in the reference, raytracer.cpp:983
+        throw std::invalid_argument("Integrator::Euler does not support RayDestination stopping conditions");
+    kr_params p;
+    fill_params(&p, method, r_max, steplim);
+    bool default_velocity = false;
+    if (!builtin_destination(dest, p.stop_kind, p.stop_params, default_velocity))
+        throw std::runtime_error("Raytracer::run_raytrace: only FlatDiscDestination, DiscWithISCODestination and FlatPlaneDestination "
+                                 "can be evaluated by the HIP kernel; a user-defined RayDestination would need per-step host callbacks");
+    trace(&p, rays, nRays);
+}
+
+// ---- single-ray forms --------------------------------------------------------------------------------------
+#define KR_SINGLE(method_, theta_expr, dest_expr)                                                       \
+    no_outfile(outfile);                                                                                \
+    (void) write_step; (void) write_rmax; (void) write_rmin; (void) write_cartesian;                   \
+    kr_params p;                                                                                        \
+    fill_params(&p, method_, rlim, steplim);                                                            \
+    theta_expr;                                                                                         \
+    dest_expr;                                                                                          \
+    const int before = rays[ray].steps;                                                                 \
+    trace(&p, &rays[ray], 1);                                                                           \
+    return std::abs(rays[ray].steps) - std::abs(before);
+
+template <typename T>
+int Raytracer<T>::propagate(int ray, const T rlim, const T thetalim, const int steplim, TextOutput* outfile, int write_step, T write_rmax,
+                            T write_rmin, bool write_cartesian)
+{
+    KR_SINGLE(Integrator::Euler, p.theta_max = thetalim, (void) 0)
+}
+
+template <typename T>
+int Raytracer<T>::propagate_rk4(int ray, const T rlim, const T thetalim, const int steplim, TextOutput* outfile, int write_step,
+                                T write_rmax, T write_rmin, bool write_cartesian)
+{
+    KR_SINGLE(Integrator::RK4, p.theta_max = thetalim, (void) 0)
+}
+
+template <typename T>
+int Raytracer<T>::propagate_rk45(int ray, const T rlim, const T thetalim, const int steplim, TextOutput* outfile, int write_step,
+                                 T write_rmax, T write_rmin, bool write_cartesian)
+{
+    KR_SINGLE(Integrator::RK45, p.theta_max = thetalim, (void) 0)
+}
+
+#define KR_DEST_OR_THROW                                                                                 \
+    bool dv = false;                                                                                     \
+    if (!builtin_destination(dest, p.stop_kind, p.stop_params, dv)) throw std::runtime_error("unsupported RayDestination subclass")
+
+template <typename T>
+int Raytracer<T>::propagate_rk4(int ray, const T rlim, RayDestination<T>* dest, const int steplim, TextOutput* outfile, int write_step,
+                                T write_rmax, T write_rmin, bool write_cartesian)
+{
+    KR_SINGLE(Integrator::RK4, (void) 0, KR_DEST_OR_THROW)
+}
+
+template <typename T>
+int Raytracer<T>::propagate_rk45(int ray, const T rlim, RayDestination<T>* dest, const int steplim, TextOutput* outfile, int write_step,
+                                 T write_rmax, T write_rmin, bool write_cartesian)
+{
+    KR_SINGLE(Integrator::RK45, (void) 0, KR_DEST_OR_THROW)
+}
+
+// ---- per-ray helpers (host), reference raytracer.cpp:480-600 ---------------------------------------------------
+namespace {
+
+template <typename T>
+struct HostMetric {
+    T g[16];
+    krhost::BLCoefficients<T> m;
+    HostMetric(T r, T theta, T a) : m(r, theta, a)
+    {
+        for (int i = 0; i < 16; i++) g[i] = 0;
+        g[0] = m.e2nu - m.omega * m.omega * m.e2psi;
+        g[3] = m.omega * m.e2psi;
+        g[12] = g[3];
+        g[5] = -m.rhosq / m.delta;
+        g[10] = -m.rhosq;
+        g[15] = -m.e2psi;
+    }
+    T contract(const T* et, const T* p) const
+    {
+        T e = 0;
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) e += g[i * 4 + j] * et[i] * p[j];
+        return e;
+    }
+};
+
+}  // namespace
+
+template <typename T>
+T Raytracer<T>::ray_redshift(T V, bool reverse, bool projradius, T r, T theta, T phi, T k, T h, T Q, int rdot_sign, int thetadot_sign,
+                             T emit, int motion)
+{
+    const T a = (reverse) ? -1 * spin : spin;
+    const HostMetric<T> gm(r, theta, a);
+    T et[] = {0, 0, 0, 0};
+    if (motion == 0) {
+        if (V == -1 && projradius)
+            V = 1 / (a + r * sin(theta) * sqrt(r * sin(theta)));
+        else if (V == -1)
+            V = 1 / (a + r * sqrt(r));
+        et[0] = (1 / sqrt(gm.m.e2nu)) / sqrt(1 - (V - gm.m.omega) * (V - gm.m.omega) * gm.m.e2psi / gm.m.e2nu);
+        et[3] = (1 / sqrt(gm.m.e2nu)) * V / sqrt(1 - (V - gm.m.omega) * (V - gm.m.omega) * gm.m.e2psi / gm.m.e2nu);
+    } else if (motion == 1) {
+        if (V < 0) V = abs(V) * (r * r - 2 * r + spin + spin) / (r * r + spin * spin);   // as in the reference (:531)
+        et[0] = 1. / sqrt(gm.g[0] + gm.g[5] * V * V);
+        et[1] = V * et[0];
+    }
+    T p[4];
+    momentum_from_consts<T>(p[0], p[1], p[2], p[3], k, h, Q, rdot_sign, thetadot_sign, r, theta, phi, spin);
+    if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
+    const T recv = gm.contract(et, p);
+    return (reverse) ? recv / emit : emit / recv;
+}
+
+template <typename T>
+T Raytracer<T>::ray_redshift(const T et[4], bool reverse, T r, T theta, T phi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T emit)
+{
+    const HostMetric<T> gm(r, theta, spin);
+    T p[4];
+    momentum_from_consts<T>(p[0], p[1], p[2], p[3], k, h, Q, rdot_sign, thetadot_sign, r, theta, phi, spin);
+    if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
+    const T recv = gm.contract(et, p);
+    return (reverse) ? recv / emit : emit / recv;
+}
+
+// ---- O(N) passes: GPU for double, host loops for float ---------------------------------------------------------
+namespace {
+
+template <typename T> struct OnDevice { static constexpr bool value = false; };
+template <> struct OnDevice<double> { static constexpr bool value = true; };
+
+inline kr_ray_f64* as_kr(Ray<double>* r) { return reinterpret_cast<kr_ray_f64*>(r); }
+inline kr_ray_f64* as_kr(Ray<float>*) { return nullptr; }
+
+}  // namespace
+
+template <typename T>
+void Raytracer<T>::redshift_start(T V, bool reverse, bool projradius)
+{
+    if (OnDevice<T>::value) {
+        check(kr_redshift_start_f64(spin, V, reverse, projradius, as_kr(rays), nRays), "kr_redshift_start");
+        return;
+    }
+    // host loop; V carries over from ray to ray once replaced, exactly like the reference's by-value parameter
+    for (int ray = 0; ray < nRays; ray++) {
+        Ray<T>& R = rays[ray];
+        const T a = (reverse) ? -1 * spin : spin;
+        const HostMetric<T> gm(R.r, R.theta, a);
+        if (V == -1 && projradius)
+            V = 1 / (a + R.r * sin(R.theta) * sqrt(R.r * sin(R.theta)));
+        else if (V == -1)
+            V = 1 / (a + R.r * sqrt(R.r));
+        const T et[] = {(1 / sqrt(gm.m.e2nu)) / sqrt(1 - (V - gm.m.omega) * (V - gm.m.omega) * gm.m.e2psi / gm.m.e2nu), 0, 0,
+                        (1 / sqrt(gm.m.e2nu)) * V / sqrt(1 - (V - gm.m.omega) * (V - gm.m.omega) * gm.m.e2psi / gm.m.e2nu)};
+        T p[4];
+        momentum_from_consts<T>(p[0], p[1], p[2], p[3], R.k, R.h, R.Q, R.rdot_sign, R.thetadot_sign, R.r, R.theta, R.phi, spin);
+        if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
+        R.emit = gm.contract(et, p);
+    }
+}
+
+template <typename T>
+void Raytracer<T>::redshift(T V, bool reverse, bool projradius, int motion)
+{
+    if (OnDevice<T>::value) {
+        check(kr_redshift_f64(spin, V, reverse, projradius, motion, as_kr(rays), nRays), "kr_redshift");
+        return;
+    }
+    for (int ray = 0; ray < nRays; ray++) {
+        Ray<T>& R = rays[ray];
+        R.redshift = ray_redshift(V, reverse, projradius, R.r, R.theta, R.phi, R.k, R.h, R.Q, R.rdot_sign, R.thetadot_sign, R.emit, motion);
+    }
+}
+
+template <typename T>
+void Raytracer<T>::redshift(RayDestination<T>* dest, bool reverse, bool projradius, int motion)
+{
+    (void) projradius; (void) motion;
+    int kind = 0;
+    double sp[4];
+    bool default_velocity = false;
+    if (OnDevice<T>::value && builtin_destination(dest, kind, sp, default_velocity) && default_velocity) {
+        check(kr_redshift_dest_f64(spin, reverse, as_kr(rays), nRays), "kr_redshift_dest");
+        return;
+    }
+    // user-defined velocity field: per-ray virtual call, host loop as in the reference (:467-476)
+    for (int ray = 0; ray < nRays; ray++) {
+        Ray<T>& R = rays[ray];
+        T et[4];
+        dest->four_velocity(R.r, R.theta, R.phi, spin, et);
+        R.redshift = ray_redshift(et, reverse, R.r, R.theta, R.phi, R.k, R.h, R.Q, R.rdot_sign, R.thetadot_sign, R.emit);
+    }
+}
+
+template <typename T>
+void Raytracer<T>::range_phi(T min, T max)
+{
+    if (OnDevice<T>::value) {
+        check(kr_range_phi_f64(min, max, as_kr(rays), nRays), "kr_range_phi");
+        return;
+    }
+    for (int ray = 0; ray < nRays; ray++) {
+        if (abs(rays[ray].phi) > 1000 || rays[ray].phi != rays[ray].phi || !(rays[ray].steps > 0)) continue;
+        while (rays[ray].phi >= max) rays[ray].phi -= 2 * M_PI;
+        while (rays[ray].phi < min) rays[ray].phi += 2 * M_PI;
+    }
+}
+
+template <typename T>
+void Raytracer<T>::calculate_momentum()
+{
+    if (OnDevice<T>::value) {
+        check(kr_calculate_momentum_f64(spin, as_kr(rays), nRays), "kr_calculate_momentum");
+        return;
+    }
+    for (int ray = 0; ray < nRays; ray++) {
+        Ray<T>& R = rays[ray];
+        momentum_from_consts<T>(R.pt, R.pr, R.ptheta, R.pphi, R.k, R.h, R.Q, R.rdot_sign, R.thetadot_sign, R.r, R.theta, R.phi, spin);
+    }
+}
+
+// ---- constants of motion for the ray sources (host, O(N)); reference raytracer.cpp:625-701 ------------------------
+template <typename T>
+void Raytracer<T>::calculate_constants(int ray, T alpha, T beta, T V, T E)
+{
+    Ray<T>& R = rays[ray];
+    const T r = R.r, th = R.theta;
+    const krhost::BLCoefficients<T> m(r, th, spin);
+    const T e2nu = m.e2nu, e2psi = m.e2psi, omega = m.omega, rhosq = m.rhosq, delta = m.delta;
+
+    // orbiting source's tetrad
+    const T et0 = (1 / sqrt(e2nu)) / sqrt(1 - (V - omega) * (V - omega) * e2psi / e2nu);
+    const T et3 = (1 / sqrt(e2nu)) * V / sqrt(1 - (V - omega) * (V - omega) * e2psi / e2nu);
+    const T e10 = (V - omega) * sqrt(e2psi / e2nu) / sqrt(e2nu - (V - omega) * (V - omega) * e2psi);
+    const T e13 = (1 / sqrt(e2nu * e2psi)) * (e2nu + V * omega * e2psi - omega * omega * e2psi) / sqrt(e2nu - (V - omega) * (V - omega) * e2psi);
+    const T e22 = -1 / sqrt(rhosq);
+    const T e31 = sqrt(delta / rhosq);
+
+    // photon 4-momentum in the source frame and its Boyer-Lindquist components
+    const T q[] = {E, E * sin(alpha) * cos(beta), E * sin(alpha) * sin(beta), E * cos(alpha)};
+    const T tdot = q[0] * et0 + q[1] * e10;
+    const T phidot = q[0] * et3 + q[1] * e13;
+    const T rdot = q[3] * e31;
+    const T thetadot = q[2] * e22;
+
+    R.k = (1 - 2 * r / rhosq) * tdot + (2 * spin * r * sin(th) * sin(th) / rhosq) * phidot;
+    R.h = phidot * ((r * r + spin * spin) * (r * r + spin * spin * cos(th) * cos(th) - 2 * r) * sin(th) * sin(th) +
+                    2 * spin * spin * r * sin(th) * sin(th) * sin(th) * sin(th));
+    R.h = R.h - 2 * spin * r * R.k * sin(th) * sin(th);
+    R.h = R.h / (r * r + spin * spin * cos(th) * cos(th) - 2 * r);
+    R.Q = rhosq * rhosq * thetadot * thetadot - (spin * R.k * cos(th) + R.h / tan(th)) * (spin * R.k * cos(th) - R.h / tan(th));
+
+    R.rdot_sign = (rdot >= 0) ? 1 : -1;
+    R.thetadot_sign = (thetadot > 0) ? 1 : -1;
+    R.rdot_flips = 0;
+    R.equatorial_crossings = 0;
+}
+
+template <typename T>
+void Raytracer<T>::calculate_constants_from_p(int ray, T pt, T pr, T ptheta, T pphi)
+{
+    (void) pt;
+    Ray<T>& R = rays[ray];
+    const T a = spin, r = R.r, theta = R.theta;
+    const T rhosq = r * r + (a * cos(theta)) * (a * cos(theta));
+    T k = (1 - 2 * r / rhosq) * pr + (2 * a * r * sin(theta) * sin(theta) / rhosq) * pphi;   // pr, as in the reference (:690)
+    T h = pphi * ((r * r + a * a) * (r * r + a * a * cos(theta) * cos(theta) - 2 * r) * sin(theta) * sin(theta) +
+                  2 * a * a * r * sin(theta) * sin(theta) * sin(theta) * sin(theta));
+    h = h - 2 * a * r * k * sin(theta) * sin(theta);
+    h = h / (r * r + a * a * cos(theta) * cos(theta) - 2 * r);
+    const T Q = rhosq * rhosq * ptheta * ptheta - (a * k * cos(theta) + h / tan(theta)) * (a * k * cos(theta) - h / tan(theta));
+    R.k = k;
+    R.h = h;
+    R.Q = Q;
+}
+
+template class Raytracer<double>;
+template class Raytracer<float>;

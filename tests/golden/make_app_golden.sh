@@ -1,0 +1,21 @@
+#!/bin/bash
+# Regenerates tests/golden/apps/*.{dat,fits,txt}: outputs of the REFERENCE's own applications (CPU build,
+# oracle/_ref/apps/, produced by dropin/build_apps.sh from the sources under /root/reference) on the par
+# files next to this script.  Build container only.  Fixtures are the apps' output files (data), nothing else.
+set -euo pipefail
+HERE=$(cd "$(dirname "$0")" && pwd)
+APPS=$HERE/../../oracle/_ref/apps
+G=$HERE/apps
+export LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6 LD_LIBRARY_PATH=/opt/conda/lib
+# emissivity*.cpp keep a pointer into a std::string that has gone out of scope when --parfile is given
+# (emissivity.cpp:22-27), so they are run from a scratch dir where the built-in default ../par/<app>.par resolves.
+W=$(mktemp -d); mkdir -p $W/par $W/run
+cp $G/emissivity.par $G/emissivity_rd.par $W/par/
+( cd $W/run && $APPS/emissivity --outfile=$G/emissivity.dat > /dev/null && $APPS/emissivity_rd --outfile=$G/emissivity_rd.dat > /dev/null )
+rm -rf $W
+rm -f $G/imageplane_rk4.fits $G/imageplane_rk45.fits
+$APPS/imageplane_disc_image --parfile=$G/imageplane_rk4.par  --outfile=$G/imageplane_rk4.fits  > /dev/null
+$APPS/imageplane_disc_image --parfile=$G/imageplane_rk45.par --outfile=$G/imageplane_rk45.fits > /dev/null
+$APPS/raytrace_rk4_test    | tail -16 > $G/raytrace_rk4_test.txt
+$APPS/emissivity_rk45_test | tail -40 > $G/emissivity_rk45_test.txt
+ls -la $G
