@@ -1,0 +1,96 @@
+"""CPU, world_size 2 over gloo: the multi-GPU sharding of bench.py (row-cyclic PointSource grids + one all-reduce of
+the emissivity histogram) is correct by construction: the union of the rank grids is exactly the refined global
+grid and the all-reduced histogram equals the single-process one.  The per-rank engine here is the oracle (no GPU
+in this container); on the GPU box the same ranks call libkrtrace and all-reduce over RCCL."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_cases as gc
+import oracle_lib as ol
+from raytrace_cpu_amd import capi
+
+sys.path.insert(0, gc.ROOT)
+import bench  # noqa: E402
+
+D = 0.08       # base grid spacing: 25 x 25 rays per rank
+NR = 30
+
+
+def _hist(spec, n_primary):
+    o = ol.oracle()
+    rays = ol.oracle_pointsource(spec)
+    o.kro_redshift_start_f64(bench.SPIN, 0.0, 0, 0, ol.ptr(rays), len(rays))
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max = capi.RK4, bench.R_MAX
+    out, st = ol.oracle_trace(p, rays, nthreads=2)
+    o.kro_range_phi_f64(-np.pi, np.pi, ol.ptr(out), len(out))
+    o.kro_redshift_f64(bench.SPIN, -1.0, 0, 0, 0, ol.ptr(out), len(out))
+    b = bench.emis_bins(capi, o.kro_kerr_isco(bench.SPIN, 1), n_primary)
+    b.nr = NR
+    b.dr = float(np.exp(np.log(bench.R_DISC / b.r_min) / NR))
+    cnt = np.zeros(NR, dtype=np.int64)
+    flux, emis, sg, stt = (np.zeros(NR) for _ in range(4))
+    dc = C.c_int64()
+    o.kro_reduce_emissivity_f64(C.byref(b), ol.ptr(out), len(out), ol.ptr(cnt), ol.ptr(flux), ol.ptr(emis), ol.ptr(sg), ol.ptr(stt), C.byref(dc))
+    h = np.concatenate([cnt.astype(np.float64), flux, emis, sg, stt, [float(dc.value)]])
+    return h, out, st
+
+
+def _n_primary(world):
+    full = bench.make_spec(capi, D, refine=world)
+    return int(((full.cosalphamax - full.cosalpha0) / full.dcosalpha) * ((full.betamax - full.beta0) / full.dbeta)), full
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_primary, _ = _n_primary(world)
+    h, out, st = _hist(bench.make_spec(capi, D, rank, world), n_primary)
+    t = torch.from_numpy(h.copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)          # the path's one exchange
+    tot = torch.tensor([float(st["rays_traced"]), float(st["steps_total"])], dtype=torch.float64)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    live = out["steps"] != -1
+    q.put((rank, t.numpy().copy(), tot.numpy().copy(), np.stack([out["alpha"][live], out["beta"][live]], 1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_cyclic_shards_reduce_to_the_global_histogram():
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+
+    n_primary, full = _n_primary(world)
+    h_full, out_full, st_full = _hist(full, n_primary)
+    # (1) every rank holds the same reduced histogram, (2) it equals the single-process histogram of the global grid
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][1][:NR], h_full[:NR])                 # counts: exact
+    np.testing.assert_allclose(res[0][1], h_full, rtol=1e-12)                   # sums: order of addition only
+    # (3) the shards partition the global ray set: same (cos alpha, beta) pairs, no overlap
+    live = out_full["steps"] != -1
+    glob = np.stack([out_full["alpha"][live], out_full["beta"][live]], 1)
+    union = np.concatenate([r[3] for r in res])
+    assert len(union) == len(glob) == int(res[0][2][0]) == st_full["rays_traced"]
+    key = lambda a: np.lexsort((a[:, 1], a[:, 0]))
+    np.testing.assert_allclose(union[key(union)], glob[key(glob)], rtol=0, atol=1e-12)
+    assert int(res[0][2][1]) == st_full["steps_total"]
