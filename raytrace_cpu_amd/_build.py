@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["kr_trace.hip", "kr_post.hip", "kr_capi.hip"]
-HEADERS = ["kr_device.hpp", "kr_common.hpp", os.path.join("..", "..", "include", "kr_trace.h")]
+HEADERS = ["kr_device.hpp", "kr_sincos.hpp", "kr_common.hpp", os.path.join("..", "..", "include", "kr_trace.h")]
 LIB = os.path.join(CSRC, "libkrtrace.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
@@ -34,13 +34,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), tag=""):
+    """tag != "": an experiment variant, built next to the product library as libkrtrace_<tag>.so (never loaded by default)."""
     deps = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     jobs = []
+    lib = LIB if not tag else LIB.replace(".so", f"_{tag}.so")
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", f"{'_' + tag if tag else ''}.o"))
         objs.append(o)
         if force or _stale(o, [s] + deps):
             jobs.append([hipcc(), *FLAGS, *extra_flags, "-c", s, "-o", o])
@@ -52,9 +54,9 @@ def build(force=False, verbose=False, extra_flags=()):
 
     with ThreadPoolExecutor(max_workers=3) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":

@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "../../include/kr_trace.h"
+#include "kr_sincos.hpp"
 
 namespace kr {
 
@@ -25,7 +26,7 @@ KR_DEV double kr_abs(double x) { return __builtin_fabs(x); }
 KR_DEV float kr_abs(float x) { return __builtin_fabsf(x); }
 KR_DEV double kr_sqrt(double x) { return __builtin_sqrt(x); }     // IEEE correctly rounded on gfx950 (checked in tests/test_gpu_primitives.py)
 KR_DEV float kr_sqrt(float x) { return __builtin_sqrtf(x); }
-KR_DEV void kr_sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+KR_DEV void kr_sincos(double x, double& s, double& c) { kr_sincos_f64(x, s, c); }
 KR_DEV void kr_sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
 KR_DEV double kr_sin(double x) { return ::sin(x); }
 KR_DEV float kr_sin(float x) { return ::sinf(x); }

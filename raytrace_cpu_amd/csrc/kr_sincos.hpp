@@ -1,0 +1,65 @@
+// kr_sincos.hpp -- compact sin/cos pair for polar angles (see the comment on kr_sincos_f64).
+// Compiles both as device code (hipcc) and as plain host C++ (g++), the latter only so that
+// tests/test_sincos_accuracy.py can measure its error against long-double libm on the CPU.
+#pragma once
+#include <math.h>
+#if defined(__HIPCC__)
+#define KR_SC_FN __device__ __forceinline__
+#else
+#define KR_SC_FN static inline
+#endif
+
+#ifndef KR_COMPACT_SINCOS
+#define KR_COMPACT_SINCOS 1
+#endif
+
+// sin and cos of a polar angle.  theta stays within a few multiples of pi (it is reflected back into [0, pi]
+// after every step and the RK stages move it by a fraction of that), so the general-purpose device sincos
+// (Payne-Hanek capable, ~90 VALU instructions, 4 calls per RK4 step = a third of the step) is replaced by:
+//   n = rint(x * 2/pi);  r = x - n*pi/2 in two FMA steps (pi/2 = P1 + P2, the first one exact for |n| < 2^10:
+//   x and n*P1 are multiples of ulp(P1) and |r| < 1), with the rounding tail of the second step kept;
+//   sin/cos of r in [-pi/4, pi/4] from the classic degree-13 / degree-14 minimax kernels with tail
+//   correction (Sun fdlibm k_sin.c / k_cos.c coefficients; < 1 ulp); quadrant fix-up by n mod 4.
+// About 45 instructions for both results.  |x| >= 1024 (never reached by a healthy ray) and non-finite inputs
+// take the library path.
+KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
+{
+#if KR_COMPACT_SINCOS
+    const double ax = __builtin_fabs(x);
+    if (__builtin_expect(!(ax < 1024.0), 0)) {
+        sincos(x, &s, &c);
+        return;
+    }
+    const double t = __builtin_rint(x * 6.36619772367581382433e-01);        // 2/pi
+    const int n = (int) t;
+    const double r0 = __builtin_fma(-t, 1.57079632679489655800e+00, x);     // P1 = fl(pi/2); exact
+    const double r = __builtin_fma(-t, 6.12323399573676603587e-17, r0);     // P2 = pi/2 - P1
+    const double y = __builtin_fma(-t, 6.12323399573676603587e-17, r0 - r); // what rounding r dropped
+    const double z = r * r;
+    // sin(r + y)
+    const double v = z * r;
+    const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double sr = r - ((z * (0.5 * y - v * ps) - y) - v * -1.66666666666666324348e-01);
+    // cos(r + y)
+    const double pc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                                                          -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double ar = __builtin_fabs(r);
+    // qx ~ |r|/4 with a short mantissa, so that 1 - qx and z/2 - qx are exact (0 below 0.3, capped at 0.28125)
+    const unsigned long long qbits = (__builtin_bit_cast(unsigned long long, ar) - 0x0020000000000000ull) & 0xFFFFFFFF00000000ull;
+    double qx = __builtin_bit_cast(double, qbits);
+    qx = (ar > 0.78125) ? 0.28125 : qx;
+    qx = (ar < 0.3) ? 0.0 : qx;
+    const double cr = (1.0 - qx) - ((0.5 * z - qx) - (z * pc - r * y));
+    // quadrant: sin -> {s, c, -s, -c}[n & 3], cos -> {c, -s, -c, s}[n & 3]
+    const bool odd = (n & 1) != 0;
+    const double ss = odd ? cr : sr;
+    const double cc = odd ? sr : cr;
+    const unsigned long long sgn_s = ((unsigned long long) (unsigned) (n & 2)) << 62;
+    const unsigned long long sgn_c = ((unsigned long long) (unsigned) ((n + 1) & 2)) << 62;
+    s = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, ss) ^ sgn_s);
+    c = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, cc) ^ sgn_c);
+#else
+    sincos(x, &s, &c);
+#endif
+}

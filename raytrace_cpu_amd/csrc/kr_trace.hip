@@ -30,6 +30,18 @@ namespace kr {
 namespace {
 
 constexpr int kBlock = 256;          // 4 independent waves per workgroup, no barriers
+#ifndef KR_MIN_WAVES
+#define KR_MIN_WAVES 1               // __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocator must allow
+#endif
+#ifndef KR_REFILL_MIN
+#define KR_REFILL_MIN 1
+#endif
+#ifndef KR_LONG_RAY_PRIO
+#define KR_LONG_RAY_PRIO 1
+#endif
+#ifndef KR_LONG_RAY_STEPS
+#define KR_LONG_RAY_STEPS 2048
+#endif
 constexpr int kCounters = 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects
 
 template <typename T> struct RayOf;
@@ -91,7 +103,7 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 // METHOD: KR_EULER / KR_RK4 / KR_RK45.  REFILL_MIN: a wave goes back to the queue when at least this many of its
 // lanes are free (or when none holds a ray).
 template <typename T, int METHOD, bool USE_DEST, int REFILL_MIN>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, KR_MIN_WAVES)
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters)
 {
     const int lane = threadIdx.x & 63;
@@ -103,6 +115,9 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     bool exhausted = false;     // wave-uniform: the queue head has passed n
     unsigned long long my_steps = 0, my_traced = 0;
     uint32_t my_attempts = 0, my_rejects = 0;
+#if KR_LONG_RAY_PRIO
+    bool has_prio = false;
+#endif
 
     for (;;) {
         const unsigned long long need = __ballot(!have);
@@ -143,6 +158,20 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
         }
 
         if (!any_have) break;   // nothing held and (exhausted or nothing needed): only reachable when exhausted
+
+#if KR_LONG_RAY_PRIO
+        // The launch cannot end before its longest ray does, and a ray advances one step per iteration of ITS wave:
+        // a wave that carries a long ray (orbiting / polar-axis rays: 2e4..1e7 steps against a median of ~450) is
+        // given issue priority over its SIMD neighbours so that the critical path runs at single-wave speed
+        // instead of at 1/(waves per SIMD) of it.  Wave-uniform, re-evaluated only when the ballot changes.
+        {
+            const bool want_prio = __any(have && s.steps > KR_LONG_RAY_STEPS);
+            if (want_prio != has_prio) {
+                has_prio = want_prio;
+                if (want_prio) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            }
+        }
+#endif
 
         if (have) {
             bool fin;
@@ -217,7 +246,7 @@ template <typename T, int METHOD, bool USE_DEST>
 int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, unsigned long long* counters, int cus,
            hipStream_t stream)
 {
-    constexpr int kRefill = 1;
+    constexpr int kRefill = KR_REFILL_MIN;
     auto kern = trace_kernel<T, METHOD, USE_DEST, kRefill>;
     int blocks_per_cu = 0;
     KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, kBlock, 0));
