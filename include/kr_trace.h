@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 1
+#define KR_ABI_VERSION 2
 
 /* error codes */
 #define KR_OK          0
@@ -118,6 +118,9 @@ typedef struct kr_stats {
     int64_t rk45_rejects;    /* RK45: trial steps rejected */
     double  kernel_ms;       /* trace kernel duration, HIP events on the launch stream */
     double  h2d_ms, d2h_ms;  /* host-buffer entry points only */
+    int64_t rk45_stationary_steps;  /* RK45: steps (included in steps_total and rk45_attempts) that were replayed as bare t/phi
+                                       additions after a captured ray reached an exact fp64 fixed point in (r, theta, step);
+                                       bit-identical to iterating them (kr_device.hpp::step_rk45) */
 } kr_stats;
 
 /* PointSource<T> ctor arguments (pointsource.h:24, pointsource.cpp:11-64) */

@@ -164,3 +164,86 @@ double ref_kerr_isco(double a, int sign) { return kerr_isco<double>(a, sign); }
 double ref_disc_velocity(double r, double a, int sign) { return disc_velocity<double>(r, a, sign); }
 
 } // extern "C"
+
+// ---- Raytracer<float> (the reference's second explicit instantiation, raytracer.cpp:1897) ---------------------
+namespace {
+struct HandleF {
+    Raytracer<float>* base = nullptr;
+    PointSource<float>* ps = nullptr;
+    ImagePlane<float>* ip = nullptr;
+};
+RayDestination<float>* make_dest_f(int kind, const double* p)
+{
+    switch (kind) {
+        case 1: return new FlatDiscDestination<float>((float) p[0]);
+        case 2: return new DiscWithISCODestination<float>((float) p[0], (float) p[1], (float) p[2]);
+        case 3: return new FlatPlaneDestination<float>((float) p[0], (float) p[1], (float) p[2]);
+        default: return nullptr;
+    }
+}
+} // namespace
+
+extern "C" {
+
+int ref_sizeof_ray_f32() { return (int) sizeof(Ray<float>); }
+
+void* ref_pointsource_new_f32(const double* pos, double V, double spin, double tol, double dcosalpha, double dbeta,
+                              double cosalpha0, double cosalphamax, double beta0, double betamax, double E)
+{
+    Quiet q;
+    float p[4] = {(float) pos[0], (float) pos[1], (float) pos[2], (float) pos[3]};
+    HandleF* h = new HandleF;
+    h->ps = new PointSource<float>(p, (float) V, (float) spin, (float) tol, (float) dcosalpha, (float) dbeta, (float) cosalpha0,
+                                   (float) cosalphamax, (float) beta0, (float) betamax, (float) E);
+    h->base = h->ps;
+    return h;
+}
+
+void* ref_imageplane_new_f32(double dist, double inc_deg, double x0, double xmax, double dx, double y0, double ymax, double dy,
+                             double spin, double phi, double precision)
+{
+    Quiet q;
+    HandleF* h = new HandleF;
+    h->ip = new ImagePlane<float>((float) dist, (float) inc_deg, (float) x0, (float) xmax, (float) dx, (float) y0, (float) ymax,
+                                  (float) dy, (float) spin, (float) phi, (float) precision);
+    h->base = h->ip;
+    return h;
+}
+
+void ref_free_f32(void* hv)
+{
+    Quiet q;
+    HandleF* h = (HandleF*) hv;
+    if (h->ps) delete h->ps;
+    if (h->ip) delete h->ip;
+    delete h;
+}
+
+int ref_count_f32(void* hv) { return ((HandleF*) hv)->base->get_count(); }
+void* ref_rays_f32(void* hv) { return ((HandleF*) hv)->base->rays; }
+void ref_set_rk45_tol_f32(void* hv, double tol) { ((HandleF*) hv)->base->set_rk45_tol((float) tol); }
+
+void ref_redshift_start_f32(void* hv, double V, int reverse, int projradius)
+{
+    Quiet q;
+    ((HandleF*) hv)->base->redshift_start((float) V, reverse != 0, projradius != 0);
+}
+
+void ref_run_thetalim_f32(void* hv, int method, double theta_max, double r_max, int steplim)
+{
+    Quiet q;
+    ((HandleF*) hv)->base->run_raytrace(method_of(method), (float) theta_max, (float) r_max, 0, nullptr, 1, -1, -1, true, steplim);
+}
+
+int ref_run_dest_f32(void* hv, int method, int dest_kind, const double* dest_params, double r_max, int steplim)
+{
+    Quiet q;
+    RayDestination<float>* d = make_dest_f(dest_kind, dest_params);
+    if (!d) return -1;
+    ((HandleF*) hv)->base->run_raytrace(d, method_of(method), (float) r_max, 0, nullptr, 1, -1, -1, true, steplim);
+    delete d;
+    return 0;
+}
+
+} // extern "C"
+

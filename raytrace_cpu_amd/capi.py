@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -35,7 +35,7 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("rays_total", "rays_traced", "steps_total", "rk45_attempts", "rk45_rejects")] + \
-               [(n, C.c_double) for n in ("kernel_ms", "h2d_ms", "d2h_ms")]
+               [(n, C.c_double) for n in ("kernel_ms", "h2d_ms", "d2h_ms")] + [("rk45_stationary_steps", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -343,10 +343,16 @@ KR_DEV void rk45_seed(Lane<T>& s, const TraceConsts<T>& c)
 // accepted) and retries on the next iteration, so a rejection never stalls the other 63 lanes.
 // attempts/rejects are per-lane counters.  Returns true when the ray has finished.
 template <typename T, bool USE_DEST>
-KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& rejects)
+KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& rejects, uint32_t& stationary_steps)
 {
     using D = Dopri<T>;
     const T a = c.a;
+
+    // snapshot of every variable that feeds back into the next outer step (for the fixed-point test below)
+    const bool fresh = !s.in_retry;
+    const T step_in = s.step;
+    const int32_t rs_in = s.rdot_sign, ts_in = s.thetadot_sign;
+    const bool rwp_in = s.r_was_positive, twp_in = s.theta_was_positive;
 
     if (!s.in_retry) {
         ++s.steps;
@@ -423,6 +429,7 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T theta_new = theta + h_try * (D::b1 * ptheta1 + D::b3 * ptheta3 + D::b4 * ptheta4 + D::b5 * ptheta5 + D::b6 * ptheta6);
     T t_new = s.t + h_try * sum_t;
     T phi_new = s.phi + h_try * sum_phi;
+    const bool inside_poles = !(theta_new < T(0)) && !(theta_new > T(kPi));
     reflect_poles(theta_new, phi_new, s.thetadot_sign);
 
     T pt7, pr7, ptheta7, pphi7;
@@ -462,6 +469,31 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     s.in_retry = false;
     s.t = t_new; s.r = r_new; s.theta = theta_new; s.phi = phi_new;
     s.pt = pt7; s.pr = pr7; s.ptheta = ptheta7; s.pphi = pphi7;
+
+    // Fixed point.  A ray captured by the hole ends up with r - r_horizon ~ 1e-14: the outer cap makes the
+    // step so small that r and theta no longer change in fp64, the ray never reaches r <= horizon, and the
+    // reference spins until RK45_STEPLIM (every such ray costs exactly 100 000 steps).
+    // If this whole outer step was ONE trial and left every fed-back variable (r, theta, running step, both
+    // signs, both turning-point flags) bit-identical to its value on entry, then every later outer step is this
+    // same pure function of the same inputs: it adds the same two increments to t and phi, sets the same status
+    // bits, and counts one step.  Replaying only those two additions gives bit-identical results; t and phi are
+    // accumulated one addition at a time, exactly as the full loop would round them.  (phi feeds back only
+    // through FlatPlaneDestination::reached, so that stop kind is excluded.)
+    if (fresh && inside_poles && s.r == r && s.theta == theta && s.step == step_in && s.rdot_sign == rs_in && s.thetadot_sign == ts_in &&
+        s.r_was_positive == rwp_in && s.theta_was_positive == twp_in && !(s.r <= c.horizon) && (!USE_DEST || c.stop_kind != KR_STOP_FLATPLANE) &&
+        s.steps < c.steplim) {
+        const T dt = h_try * sum_t, dphi = h_try * sum_phi;
+        const int32_t remaining = c.steplim - s.steps;
+        for (int32_t i = 0; i < remaining; ++i) {
+            s.t = s.t + dt;
+            s.phi = s.phi + dphi;
+        }
+        s.steps = c.steplim;
+        attempts += (uint32_t) remaining;
+        if (!(err_norm <= T(1))) rejects += (uint32_t) remaining;
+        stationary_steps += (uint32_t) remaining;
+        return true;
+    }
 
     if (crossed_equator(s.theta_eq_prev, s.theta)) ++s.eq_cross;   // once per accepted outer step (:1542-1544)
     s.theta_eq_prev = s.theta;

@@ -42,7 +42,7 @@ constexpr int kBlock = 256;          // 4 independent waves per workgroup, no ba
 #ifndef KR_LONG_RAY_STEPS
 #define KR_LONG_RAY_STEPS 2048
 #endif
-constexpr int kCounters = 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects
+constexpr int kCounters = 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps
 
 template <typename T> struct RayOf;
 template <> struct RayOf<double> { using type = kr_ray_f64; };
@@ -114,7 +114,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     bool have = false;          // this lane holds a ray
     bool exhausted = false;     // wave-uniform: the queue head has passed n
     unsigned long long my_steps = 0, my_traced = 0;
-    uint32_t my_attempts = 0, my_rejects = 0;
+    uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0;
 #if KR_LONG_RAY_PRIO
     bool has_prio = false;
 #endif
@@ -177,7 +177,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
             bool fin;
             if (METHOD == KR_EULER) fin = step_fixed<T, false, USE_DEST>(s, c);
             else if (METHOD == KR_RK4) fin = step_fixed<T, true, USE_DEST>(s, c);
-            else fin = step_rk45<T, USE_DEST>(s, c, my_attempts, my_rejects);
+            else fin = step_rk45<T, USE_DEST>(s, c, my_attempts, my_rejects, my_stationary);
             if (fin) {
                 my_steps += (unsigned long long) s.steps;
                 const int32_t out_steps = finish_status<T, USE_DEST>(s, c);
@@ -192,7 +192,9 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     const unsigned long long w_steps = wave_sum<T>(my_steps);
     const unsigned long long w_att = wave_sum<T>((unsigned long long) my_attempts);
     const unsigned long long w_rej = wave_sum<T>((unsigned long long) my_rejects);
+    const unsigned long long w_sta = wave_sum<T>((unsigned long long) my_stationary);
     if (lane == 0) {
+        if (w_sta) atomicAdd(&counters[5], w_sta);
         if (w_traced) atomicAdd(&counters[1], w_traced);
         if (w_steps) atomicAdd(&counters[2], w_steps);
         if (w_att) atomicAdd(&counters[3], w_att);
@@ -317,6 +319,7 @@ int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, k
         stats->steps_total = (int64_t) h[2];
         stats->rk45_attempts = (int64_t) h[3];
         stats->rk45_rejects = (int64_t) h[4];
+        stats->rk45_stationary_steps = (int64_t) h[5];
         stats->kernel_ms = ms;
     }
     return KR_OK;

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/f32_*.npz from the compiled reference's FLOAT instantiation (Raytracer<float>,
+reference raytracer.cpp:1897) through oracle/_ref/libkr_ref.so.  Build container only.  There is no float oracle
+restatement: the f32 HIP kernels are pinned directly by these reference outputs.
+  init / final__<run>: 84-B Ray<float> records (fields the reference leaves indeterminate are zeroed)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import golden_cases as gc  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+from raytrace_cpu_amd import capi  # noqa: E402
+
+P = C.POINTER
+_vp, _dbl, _int = C.c_void_p, C.c_double, C.c_int
+
+
+def lib():
+    L = ol.ref()
+    protos = {
+        "ref_pointsource_new_f32": (_vp, [P(_dbl)] + [_dbl] * 10),
+        "ref_imageplane_new_f32": (_vp, [_dbl] * 11),
+        "ref_free_f32": (None, [_vp]), "ref_count_f32": (_int, [_vp]), "ref_rays_f32": (_vp, [_vp]),
+        "ref_set_rk45_tol_f32": (None, [_vp, _dbl]),
+        "ref_redshift_start_f32": (None, [_vp, _dbl, _int, _int]),
+        "ref_run_thetalim_f32": (None, [_vp, _int, _dbl, _dbl, _int]),
+        "ref_run_dest_f32": (_int, [_vp, _int, _int, P(_dbl), _dbl, _int]),
+    }
+    for n, (r, a) in protos.items():
+        f = getattr(L, n)
+        f.restype, f.argtypes = r, a
+    return L
+
+
+def run(L, case, params):
+    s = case["source"]
+    ip = gc.is_imageplane(case)
+    if ip:
+        h = L.ref_imageplane_new_f32(s.dist, s.inc_deg, s.x0, s.xmax, s.dx, s.y0, s.ymax, s.dy, s.spin, s.phi0, s.precision)
+    else:
+        h = L.ref_pointsource_new_f32((C.c_double * 4)(*s.pos), s.V, s.spin, s.tol, s.dcosalpha, s.dbeta, s.cosalpha0, s.cosalphamax, s.beta0, s.betamax, s.E)
+    n = L.ref_count_f32(h)
+    view = np.frombuffer((C.c_char * (n * 84)).from_address(L.ref_rays_f32(h)), dtype=capi.RAY_F32)
+    dead = view["steps"] == -1
+    z = np.zeros(1, dtype=capi.RAY_F32)
+    z["steps"] = -1
+    view[dead] = z
+    if ip:
+        view["rdot_flips"] = 0
+        view["equatorial_crossings"] = 0
+    view["emit"][~dead] = 0
+    view["redshift"][~dead] = 0
+    L.ref_redshift_start_f32(h, *case["start"])
+    init = view.copy()
+    L.ref_set_rk45_tol_f32(h, params.rk45_tol)
+    if params.stop_kind == capi.STOP_THETA:
+        L.ref_run_thetalim_f32(h, params.integrator, params.theta_max, params.r_max, params.steplim)
+    else:
+        assert L.ref_run_dest_f32(h, params.integrator, params.stop_kind, (C.c_double * 4)(*params.stop_params), params.r_max, params.steplim) == 0
+    final = view.copy()
+    L.ref_free_f32(h)
+    return init, final
+
+
+F32_RUNS = {"ps_h10": ("euler", "rk4", "rk45"), "ip15": ("rk4", "rk4_isco")}
+F32_STEPLIM = 20000     # in float a few polar-axis rays never leave MIN_STEP stepping and would burn STEPLIM = 1e7 steps
+
+if __name__ == "__main__":
+    L = lib()
+    cases = gc.cases()
+    for name, runs in F32_RUNS.items():
+        out = {}
+        for r in runs:
+            init, final = run(L, cases[name], capi.copy_params(cases[name]["runs"][r], steplim=F32_STEPLIM))
+            out["init"] = init
+            out[f"final__{r}"] = final
+            live = final["steps"] != -1
+            print(name, r, len(init), "rays; steps sum", int(np.abs(final["steps"][live].astype(np.int64)).sum()), "steplim rays", int((final["steps"] < -1).sum()))
+        path = os.path.join(gc.GOLDEN_DIR, f"f32_{name}.npz")
+        np.savez_compressed(path, **out)
+        print(" ->", path, os.path.getsize(path) // 1024, "KiB")
