@@ -131,13 +131,98 @@ def cpu_baseline(args, capi, api, integrator, d_full):
     }
 
 
+class EmissivityWorkload:
+    """BASELINE configs[1] (and, with --integrator rk45, the app's own configs[0] integrator)."""
+    name = "emissivity"
+
+    def __init__(self, args, lib, capi, api, rank, world):
+        self.lib, self.capi, self.api = lib, capi, api
+        self.method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[args.integrator]
+        self.d = grid_spacing_for(args.rays or 1e7)
+        self.spec = make_spec(capi, self.d, rank, world)
+        self.n, self.n_ca, self.n_b = api.pointsource_count(self.spec)
+        full = make_spec(capi, self.d, refine=world)     # the global grid, for the flux normalisation
+        n_primary = int(((full.cosalphamax - full.cosalpha0) / full.dcosalpha) * ((full.betamax - full.beta0) / full.dbeta))
+        self.bins = emis_bins(capi, lib.kr_kerr_isco(SPIN, 1), n_primary)
+        self.p = capi.default_params(SPIN)
+        self.p.integrator, self.p.r_max = self.method, R_MAX
+        self.result_words = 5 * NR + 1
+        self.describe = (f"PointSource emissivity lamp-post h=10 a=0.998 V=0, {args.integrator.upper()}, theta_max=pi/2 r_max=1000 "
+                         f"(BASELINE configs[1]); grid {self.n_ca}x{self.n_b} per GPU")
+        self.pipeline = "pointsource_init+redshift_start+trace+range_phi+redshift+emissivity_histogram"
+        self.sharding = f"row-cyclic over {world} rank(s)"
+
+    def step(self, d_rays, d_res, stream):
+        lib, capi, vp = self.lib, self.capi, C.c_void_p
+        n = self.n
+        capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(self.spec), vp(d_rays), n, vp(stream)), "init")
+        capi.check(lib, lib.kr_redshift_start_dev_f64(SPIN, 0.0, 0, 0, vp(d_rays), n, vp(stream)), "redshift_start")
+        st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
+        capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(d_rays), n, vp(stream)), "range_phi")
+        capi.check(lib, lib.kr_redshift_dev_f64(SPIN, -1.0, 0, 0, 0, vp(d_rays), n, vp(stream)), "redshift")
+        capi.check(lib, lib.kr_reduce_emissivity_dev_f64(C.byref(self.bins), vp(d_rays), n, vp(d_res), vp(stream)), "reduce")
+        return st
+
+    def summary(self, h):
+        return {"disc_hits": float(h[5 * NR])}
+
+
+class ImagePlaneWorkload:
+    """BASELINE configs[3]: imageplane_disc_image geometry (par_example: dist 1e4, incl 80, +-30, r_disc 30, q = 3), img_N = N = 4096
+    -> 4097^2 rays, RK4 (RK45 never returns on the (0,0) pixel in the reference), ray-cyclic shards, 7 image planes reduced."""
+    name = "imageplane"
+
+    def __init__(self, args, lib, capi, api, rank, world):
+        self.lib, self.capi, self.api = lib, capi, api
+        self.method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[args.integrator]
+        N = int(round(math.sqrt(args.rays))) - 1 if args.rays else 4096
+        s = capi.ImagePlaneSpec()
+        s.dist, s.inc_deg, s.x0, s.xmax, s.y0, s.ymax = 10000.0, 80.0, -30.0, 30.0, -30.0, 30.0
+        s.dx = s.dy = 60.0 / N
+        s.spin, s.phi0, s.precision = SPIN, 0.0, 100.0
+        self.spec, self.N = s, N
+        total, nx, ny = api.imageplane_count(s)
+        self.total, self.first, self.stride = total, rank, world
+        self.n = (total - rank + world - 1) // world
+        b = capi.ImageBins()
+        b.x0, b.y0, b.img_dx, b.img_dy = s.x0, s.y0, 60.0 / N, 60.0 / N
+        b.r_isco, b.r_disc = lib.kr_kerr_isco(SPIN, 1), 30.0
+        b.q1, b.rb1, b.q2, b.rb2, b.q3 = 3.0, 4.0, 3.0, 10.0, 3.0
+        b.img_nx, b.img_ny, b.flip_image, b.pad = N, N, 1, 0
+        self.bins = b
+        self.p = capi.default_params(-SPIN)              # ImagePlane stores the spin negated (imageplane.cpp:12)
+        self.p.integrator, self.p.r_max = self.method, 1.1 * s.dist
+        self.p.flags |= (3 << 8)                         # KR_FLAG_BLOCKS_PER_CU(3): no long-ray tail on this workload (max ~2000 steps)
+        self.result_words = 7 * N * N + 1
+        self.describe = (f"ImagePlane disc image dist=1e4 incl=80 a=0.998 x,y in +-30, {nx}x{ny} rays, img {N}x{N}, {args.integrator.upper()}, "
+                         f"r_max=1.1*dist (BASELINE configs[3])")
+        self.pipeline = "imageplane_init+redshift_start+trace+redshift+range_phi+image_planes"
+        self.sharding = f"ray-cyclic over {world} rank(s)"
+
+    def step(self, d_rays, d_res, stream):
+        lib, capi, vp = self.lib, self.capi, C.c_void_p
+        n = self.n
+        capi.check(lib, lib.kr_imageplane_init_strided_dev_f64(C.byref(self.spec), self.first, self.stride, vp(d_rays), n, vp(stream)), "init")
+        capi.check(lib, lib.kr_redshift_start_dev_f64(-SPIN, 0.0, 1, 0, vp(d_rays), n, vp(stream)), "redshift_start")
+        st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
+        capi.check(lib, lib.kr_redshift_dev_f64(-SPIN, -1.0, 1, 0, 0, vp(d_rays), n, vp(stream)), "redshift")
+        capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(d_rays), n, vp(stream)), "range_phi")
+        capi.check(lib, lib.kr_reduce_image_dev_f64(C.byref(self.bins), vp(d_rays), n, vp(d_res), vp(stream)), "reduce")
+        return st
+
+    def summary(self, h):
+        return {"disc_hits": float(h[-1]), "lit_pixels": int((h[: self.N * self.N] > 0).sum())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rays", type=float, default=1e7, help="rays per GPU (BASELINE configs[1]: 1e7)")
+    ap.add_argument("--workload", default="emissivity", choices=["emissivity", "imageplane"])
+    ap.add_argument("--rays", type=float, default=0, help="rays per GPU (default: 1e7 emissivity = BASELINE configs[1]; 4097^2 imageplane = configs[3])")
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
+    ap.add_argument("--fast-math", action="store_true", help="KR_FLAG_FAST_MATH (opt-in; see include/kr_trace.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=float, default=0)
     args = ap.parse_args()
@@ -162,33 +247,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[args.integrator]
-    d = grid_spacing_for(args.rays)
-    spec = make_spec(capi, d, rank, world)
-    n, n_ca, n_b = api.pointsource_count(spec)
-    full = make_spec(capi, d, refine=world)     # the global grid, for the flux normalisation
-    n_primary = int(((full.cosalphamax - full.cosalpha0) / full.dcosalpha) * ((full.betamax - full.beta0) / full.dbeta))
-    isco = lib.kr_kerr_isco(SPIN, 1)
-    bins = emis_bins(capi, isco, n_primary)
-    p = capi.default_params(SPIN)
-    p.integrator, p.r_max = method, R_MAX
-
+    wl = (EmissivityWorkload if args.workload == "emissivity" else ImagePlaneWorkload)(args, lib, capi, api, rank, world)
+    if args.fast_math:
+        wl.p.flags |= capi.FLAG_FAST_MATH
+    n = wl.n
     rays = torch.empty(n * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda")
-    hist = torch.zeros(5 * NR + 1, dtype=torch.float64, device="cuda")
+    res = torch.zeros(wl.result_words, dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    d_rays, d_hist = rays.data_ptr(), hist.data_ptr()
-    vp = C.c_void_p
+    d_rays, d_res = rays.data_ptr(), res.data_ptr()
 
     def one_step():
-        hist.zero_()
-        capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(spec), vp(d_rays), n, vp(stream)), "init")
-        capi.check(lib, lib.kr_redshift_start_dev_f64(SPIN, 0.0, 0, 0, vp(d_rays), n, vp(stream)), "redshift_start")
-        st = api.trace_dev(p, d_rays, n, stream=stream, want_stats=True)
-        capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(d_rays), n, vp(stream)), "range_phi")
-        capi.check(lib, lib.kr_redshift_dev_f64(SPIN, -1.0, 0, 0, 0, vp(d_rays), n, vp(stream)), "redshift")
-        capi.check(lib, lib.kr_reduce_emissivity_dev_f64(C.byref(bins), vp(d_rays), n, vp(d_hist), vp(stream)), "reduce")
+        res.zero_()
+        st = wl.step(d_rays, d_res, stream)
         if dist is not None:
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM)      # RCCL over xGMI: the path's one exchange
+            dist.all_reduce(res, op=dist.ReduceOp.SUM)      # RCCL over xGMI: the path's one exchange
         return st
 
     def fence():
@@ -200,11 +272,11 @@ def main():
         one_step()
     fence()
     t0 = time.perf_counter()
-    kernel_ms, steps_total, traced = [], 0, 0
+    kernel_ms, steps_total, traced, stats_last = [], 0, 0, {}
     for _ in range(args.steps):
         st = one_step()
         kernel_ms.append(st["kernel_ms"])
-        steps_total, traced = st["steps_total"], st["rays_traced"]
+        steps_total, traced, stats_last = st["steps_total"], st["rays_traced"], st
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -217,46 +289,77 @@ def main():
     else:
         traced_all, steps_all = traced, steps_total
 
-    h = hist.cpu().numpy()
+    h = res.cpu().numpy()
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        flop = FLOP_PER_STEP[args.integrator] * steps_total          # this rank's launch
+        units = stats_last["rk45_attempts"] if args.integrator == "rk45" else steps_total     # RK45 work unit = one trial step
+        flop = FLOP_PER_STEP[args.integrator] * units                                            # this rank's launch
         achieved_tflops = flop / (avg_kernel_ms * 1e-3) / 1e12
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "trace_kernel_hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.integrator)
+                traffic = json.load(open(tfile)).get(f"{args.workload}_{args.integrator}")
             except Exception:
                 traffic = None
         out = {
             "metric": "rays_per_sec", "value": traced_all * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"PointSource emissivity lamp-post h=10 a=0.998 V=0, {args.integrator.upper()} fixed tol, theta_max=pi/2 r_max=1000 "
-                                   f"(BASELINE configs[1]); grid {n_ca}x{n_b} per GPU", "rays_per_gpu": int(traced),
-                       "allocated_rays_per_gpu": int(n), "rays_total": int(traced_all), "integrator": args.integrator,
-                       "pipeline": "init+redshift_start+trace+range_phi+redshift+histogram" + ("+rccl_allreduce" if world > 1 else ""),
-                       "sharding": f"row-cyclic over {world} rank(s)"},
+            "config": {"workload": wl.describe, "rays_per_gpu": int(traced), "allocated_rays_per_gpu": int(n), "rays_total": int(traced_all),
+                       "integrator": args.integrator, "arithmetic": "fast_math (opt-in)" if args.fast_math else "strict IEEE, reference association", "pipeline": wl.pipeline + ("+rccl_allreduce" if world > 1 else ""), "sharding": wl.sharding},
             "rk_steps_per_sec": steps_all * args.steps / elapsed,
             "rk_steps_per_launch": int(steps_total), "mean_steps_per_ray": steps_total / max(traced, 1),
-            "disc_hits": float(h[5 * NR]),
             "roofline": {"bound": "valu_fp64", "kernel": "kr::trace_kernel<double>", "achieved": achieved_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
-                         "flop_per_step": FLOP_PER_STEP[args.integrator], "avg_kernel_ms": avg_kernel_ms,
+                         "flop_per_step": FLOP_PER_STEP[args.integrator], "work_units_per_launch": int(units), "avg_kernel_ms": avg_kernel_ms,
                          "kernel_steps_per_sec": steps_total / (avg_kernel_ms * 1e-3),
                          "hbm": {"algorithmic_bytes": 288 * int(traced), "achieved_gbs": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9,
                                  "peak_gbs": HBM_PEAK_GBS, "frac": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "traffic": traffic,
                          "note": "latency-bound scalar fp64 ODE: neither HBM nor MFMA bounds it (SURVEY.md 8d); priced against vector fp64 peak"},
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, capi, api, method, d)
+        out.update(wl.summary(h))
+        if args.integrator == "rk45":
+            out["rk45"] = {k: int(stats_last[k]) for k in ("rk45_attempts", "rk45_rejects", "rk45_stationary_steps")}
+        if not args.no_cpu_baseline and args.workload == "emissivity":
+            out["cpu_baseline"] = cpu_baseline(args, capi, api, wl.method, wl.d)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_imageplane(args, capi, api, wl)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline_imageplane(args, capi, api, wl):
+    """The reference's ImagePlane<double> + run_raytrace on a coarser grid of the same plane, on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    N = int(math.sqrt(args.cpu_sample_rays or 20000 * cores)) | 1        # odd: no pixel at exactly (0,0)
+    spec = ol.imageplane_spec(10000.0, 80.0, -30.0, 30.0, 60.0 / N, -30.0, 30.0, 60.0 / N, SPIN)
+    p = capi.copy_params(wl.p)
+    kind = "reference" if ol.ref() is not None else "port"
+    if kind == "reference":
+        src = ol.RefSource(spec)
+        src.lib.ref_redshift_start(src.h, 0.0, 1, 0)
+        t0 = time.perf_counter()
+        src.run(p)
+        wall = time.perf_counter() - t0
+        out = src.snapshot()
+        src.close()
+    else:
+        init = ol.oracle_imageplane(spec)
+        ol.oracle().kro_redshift_start_f64(-SPIN, 0.0, 1, 0, ol.ptr(init), len(init))
+        t0 = time.perf_counter()
+        out, _ = ol.oracle_trace(p, init, nthreads=cores)
+        wall = time.perf_counter() - t0
+    live = out["steps"] != -1
+    steps = int(np.abs(out["steps"][live].astype(np.int64)).sum())
+    return {"value": int(live.sum()) / wall, "unit": "rays/s", "cores": cores, "kind": kind, "steps_per_sec": steps / wall, "wall_s": wall,
+            "sample": f"same image plane on a {N + 1}x{N + 1} ray grid: {int(live.sum())} rays, {steps} steps, run_raytrace only"}
 
 
 if __name__ == "__main__":

@@ -61,6 +61,14 @@ extern "C" {
  * (raytracer.cpp:1438-1541); the device path ends the ray and sets this bit instead. */
 #define KR_STATUS_NAN         (1 << 6)
 
+/* kr_params.flags */
+#define KR_FLAG_FAST_MATH     (1 << 0)  /* f64 trace only: same formulas with shared reciprocals, Newton-refined rcp/rsq and FMA
+                                           contraction instead of IEEE division/sqrt (a few ulp per operation; ~1.4x faster).
+                                           0 = strict: the reference's association with IEEE + - * / sqrt, no contraction. */
+
+#define KR_FLAG_BLOCKS_PER_CU(n)      (((n) & 0xF) << 8)   /* resident 256-thread workgroups per CU for the trace kernel, 0 = default (2) */
+#define KR_FLAG_GET_BLOCKS_PER_CU(f)  (((f) >> 8) & 0xF)
+
 /* defaults, raytracer.h:19-44 */
 #define KR_PRECISION        100.0
 #define KR_THETA_PRECISION  50.0
@@ -106,7 +114,7 @@ typedef struct kr_params {
     int32_t integrator;      /* KR_EULER / KR_RK4 / KR_RK45 */
     int32_t stop_kind;       /* KR_STOP_* */
     int32_t steplim;         /* <=0: STEPLIM for Euler/RK4, RK45_STEPLIM for RK45 (raytracer.cpp:80) */
-    int32_t flags;           /* reserved, 0 */
+    int32_t flags;           /* KR_FLAG_* */
 } kr_params;
 
 /* counters gathered by the trace kernel (what integrator_perf_test.cpp:82-93 derives on the host) */
@@ -205,6 +213,10 @@ int kr_pointsource_init_f64(const kr_pointsource* s, kr_ray_f64* rays, int64_t n
 int kr_pointsource_init_dev_f64(const kr_pointsource* s, void* d_rays, int64_t n, void* stream);
 int kr_imageplane_init_f64(const kr_imageplane* s, kr_ray_f64* rays, int64_t n);
 int kr_imageplane_init_dev_f64(const kr_imageplane* s, void* d_rays, int64_t n, void* stream);
+/* shard forms of the two ctors: slot k of d_rays receives ray (first + k*stride) of the source's own array, k < count.
+ * Rank r of R uses first = r, stride = R: ray-cyclic sharding, nothing else has to be exchanged before the reducers. */
+int kr_pointsource_init_strided_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, void* d_rays, int64_t count, void* stream);
+int kr_imageplane_init_strided_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, void* d_rays, int64_t count, void* stream);
 
 /* ---- reducers of the two target apps --------------------------------------------------------- */
 /* emissivity.cpp:96-126.  Outputs (length nr each): count, flux, emis, sum_redshift, sum_time -- the raw

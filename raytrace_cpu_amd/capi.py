@@ -17,6 +17,7 @@ STOP_THETA, STOP_FLATDISC, STOP_DISC_ISCO, STOP_FLATPLANE = 0, 1, 2, 3
 STATUS_DEST, STATUS_HORIZON, STATUS_RLIM, STATUS_STEPLIM = 1, 2, 4, 8
 STATUS_ERGO, STATUS_NEG_ENERGY, STATUS_NAN = 16, 32, 64
 STEPLIM, RK45_STEPLIM, MIN_STEP = 10_000_000, 100_000, 1e-3
+FLAG_FAST_MATH = 1
 
 # Ray<double> / Ray<float>  (reference src/raytracer/raytracer.h:65-78)
 _F64 = [(n, "<f8") for n in ("t", "r", "theta", "phi", "pt", "pr", "ptheta", "pphi", "k", "h", "Q", "emit", "redshift")]
@@ -121,6 +122,8 @@ PROTOTYPES = {
     "kr_pointsource_init_dev_f64": (_int, [P(PointSourceSpec), _vp, _i64, _vp]),
     "kr_imageplane_init_f64": (_int, [P(ImagePlaneSpec), _vp, _i64]),
     "kr_imageplane_init_dev_f64": (_int, [P(ImagePlaneSpec), _vp, _i64, _vp]),
+    "kr_pointsource_init_strided_dev_f64": (_int, [P(PointSourceSpec), _i64, _i64, _vp, _i64, _vp]),
+    "kr_imageplane_init_strided_dev_f64": (_int, [P(ImagePlaneSpec), _i64, _i64, _vp, _i64, _vp]),
     "kr_reduce_emissivity_f64": (_int, [P(EmisBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
     "kr_reduce_emissivity_dev_f64": (_int, [P(EmisBins), _vp, _i64, _vp, _vp]),
     "kr_reduce_image_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(_i64)]),

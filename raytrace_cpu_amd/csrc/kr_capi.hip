@@ -22,8 +22,8 @@ int redshift_dev(double spin, double V, int reverse, int projradius, int motion,
 int redshift_dest_dev(double spin, int reverse, void* d, int64_t n, hipStream_t st);
 int range_phi_dev(double lo, double hi, void* d, int64_t n, hipStream_t st);
 int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st);
-int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, hipStream_t st);
-int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, hipStream_t st);
+int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st);
+int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st);
 int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st);
 int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st);
 
@@ -274,26 +274,41 @@ int kr_pointsource_init_dev_f64(const kr_pointsource* s, void* d, int64_t n, voi
 {
     if (!s) { set_error("kr_pointsource_init: null spec"); return KR_EINVAL; }
     int rc = require_device();
-    return rc != KR_OK ? rc : pointsource_init_dev(s, d, n, (hipStream_t) st);
+    return rc != KR_OK ? rc : pointsource_init_dev(s, d, n, 0, 1, (hipStream_t) st);
 }
 int kr_pointsource_init_f64(const kr_pointsource* s, kr_ray_f64* rays, int64_t n)
 {
     if (!s) { set_error("kr_pointsource_init: null spec"); return KR_EINVAL; }
     return with_staged_rays(rays, n, sizeof(kr_ray_f64), false, true, nullptr,
-                            [&](void* d) { return pointsource_init_dev(s, d, n, nullptr); });
+                            [&](void* d) { return pointsource_init_dev(s, d, n, 0, 1, nullptr); });
 }
 
 int kr_imageplane_init_dev_f64(const kr_imageplane* s, void* d, int64_t n, void* st)
 {
     if (!s) { set_error("kr_imageplane_init: null spec"); return KR_EINVAL; }
     int rc = require_device();
-    return rc != KR_OK ? rc : imageplane_init_dev(s, d, n, (hipStream_t) st);
+    return rc != KR_OK ? rc : imageplane_init_dev(s, d, n, 0, 1, (hipStream_t) st);
 }
 int kr_imageplane_init_f64(const kr_imageplane* s, kr_ray_f64* rays, int64_t n)
 {
     if (!s) { set_error("kr_imageplane_init: null spec"); return KR_EINVAL; }
     return with_staged_rays(rays, n, sizeof(kr_ray_f64), false, true, nullptr,
-                            [&](void* d) { return imageplane_init_dev(s, d, n, nullptr); });
+                            [&](void* d) { return imageplane_init_dev(s, d, n, 0, 1, nullptr); });
+}
+
+// strided forms: slot k of d_rays receives ray (first + k*stride) of the source's array -- the multi-GPU shard of rank r
+// of R is (first = r, stride = R, count = ceil((total - r) / R)); no rank ever materialises another rank's rays.
+int kr_pointsource_init_strided_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, void* d, int64_t count, void* st)
+{
+    if (!s) { set_error("kr_pointsource_init: null spec"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : pointsource_init_dev(s, d, count, first, stride, (hipStream_t) st);
+}
+int kr_imageplane_init_strided_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, void* d, int64_t count, void* st)
+{
+    if (!s) { set_error("kr_imageplane_init: null spec"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : imageplane_init_dev(s, d, count, first, stride, (hipStream_t) st);
 }
 
 // ---- reducers ------------------------------------------------------------------------------------------------

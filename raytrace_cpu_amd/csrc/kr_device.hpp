@@ -56,6 +56,7 @@ template <typename T> struct TraceConsts {
     T a, horizon, rlim, thetalim;
     T precision, theta_precision, max_tstep, maxtstep_rlim, max_phistep, tol;
     T sp0, sp1, sp2;        // stop_params
+    T inv_precision, inv_theta_precision;   // fast-arithmetic path only
     int32_t steplim;
     int32_t stop_kind;
 };
@@ -158,6 +159,127 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
     return false;
 }
 
+
+// ==== fast-arithmetic path (kr_params.flags & KR_FLAG_FAST_MATH, double only) =====================================
+// On gfx950 an IEEE fp64 division costs ~67 SIMD-cycles per wave-instruction and an IEEE sqrt ~92, against ~5.4
+// for an FMA (scripts/microbench/fp64_peak.hip); the reference's formulation has 5 divisions + 2 square roots per
+// derivative evaluation and 6-9 more divisions in the step heuristic, i.e. about half of an RK4 step.  This path
+// evaluates the SAME formulas with one reciprocal per derivative evaluation (1/(rho^2 Delta sin^2 theta), from which
+// 1/(rho^2 Delta), 1/rho^2 and 1/sin^2 follow by multiplication), reciprocal-multiply in the heuristic, Newton-refined
+// v_rcp_f64 / v_rsq_f64 (<= ~1 ulp) and FMA contraction.  Results differ from the strict path by a few ulp per
+// operation -- the same order as the libm difference that already separates the strict path from the CPU -- and are
+// held to the same parity tolerances (tests/test_gpu_parity.py runs both).
+KR_DEV double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+KR_DEV double fast_sqrt(double x)      // x >= 0 (callers pass |.|)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x == 0.0 || x == __builtin_inf()) ? x : g;
+}
+
+struct FastAux { double rhosq, sin2theta, inv_rhosq; };
+
+// momentum_from_consts (kerr.h:300-335) with a single reciprocal
+KR_DEV void momentum_fast(double& pt, double& pr, double& ptheta, double& pphi, double k, double h, double Q, int rdot_sign,
+                          int thetadot_sign, double r, double theta, double a, FastAux* aux = nullptr, double* thetadotsq_o = nullptr,
+                          double* rdotsq_o = nullptr)
+{
+#pragma clang fp contract(fast)
+    double s, c;
+    kr_sincos_f64(theta, s, c);
+    const double s2 = s * s;
+    const double ac = a * c;
+    const double r2 = r * r;
+    const double rhosq = r2 + ac * ac;
+    const double delta = r2 - 2 * r + a * a;
+    const double rd = rhosq * delta;
+    const double inv = fast_rcp(rd * s2);          // 1 / (rho^2 Delta sin^2)
+    const double inv_rd = inv * s2;                // 1 / (rho^2 Delta)
+    const double inv_rho = inv_rd * delta;         // 1 / rho^2
+    const double inv_s2 = inv * rd;                // 1 / sin^2
+    const double ar2 = 2 * a * r;
+
+    pt = ((rhosq * (r2 + a * a) + ar2 * a * s2) * k - ar2 * h) * inv_rd;
+    pphi = (ar2 * s2 * k + (rhosq - 2 * r) * h) * inv;
+
+    const double kac = k * ac;
+    const double hcs = h * c * s * inv_s2;         // h cos / sin
+    const double thsq = (Q + (kac + hcs) * (kac - hcs)) * (inv_rho * inv_rho);
+    ptheta = fast_sqrt(__builtin_fabs(thsq)) * thetadot_sign;
+
+    const double rsq = (k * pt - h * pphi - rhosq * ptheta * ptheta) * delta * inv_rho;
+    pr = fast_sqrt(__builtin_fabs(rsq)) * rdot_sign;
+    if (aux) { aux->rhosq = rhosq; aux->sin2theta = s2; aux->inv_rhosq = inv_rho; }
+    if (thetadotsq_o) *thetadotsq_o = thsq;
+    if (rdotsq_o) *rdotsq_o = rsq;
+}
+
+// k1 with the turning-point logic (see k1_with_flips) on the fast path
+KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
+{
+#pragma clang fp contract(fast)
+    const double r = s.r, theta = s.theta, k = s.k, h = s.h;
+    double sn, c;
+    kr_sincos_f64(theta, sn, c);
+    const double s2 = sn * sn;
+    const double ac = a * c;
+    const double r2 = r * r;
+    const double rhosq = r2 + ac * ac;
+    const double delta = r2 - 2 * r + a * a;
+    const double rd = rhosq * delta;
+    const double inv = fast_rcp(rd * s2);
+    const double inv_rd = inv * s2;
+    const double inv_rho = inv_rd * delta;
+    const double inv_s2 = inv * rd;
+    const double ar2 = 2 * a * r;
+
+    s.pt = ((rhosq * (r2 + a * a) + ar2 * a * s2) * k - ar2 * h) * inv_rd;
+    s.pphi = (ar2 * s2 * k + (rhosq - 2 * r) * h) * inv;
+
+    const double kac = k * ac;
+    const double hcs = h * c * sn * inv_s2;
+    const double thetadotsq = (s.Q + (kac + hcs) * (kac - hcs)) * (inv_rho * inv_rho);
+    if (thetadotsq < 0 && s.theta_was_positive) {
+        s.thetadot_sign = -s.thetadot_sign;
+        s.theta_was_positive = false;
+        return true;
+    }
+    if (thetadotsq >= 0) s.theta_was_positive = true;
+    s.ptheta = fast_sqrt(__builtin_fabs(thetadotsq)) * s.thetadot_sign;
+
+    const double rdotsq = (k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta) * delta * inv_rho;
+    if (rdotsq <= 0 && s.r_was_positive) {
+        s.rdot_sign = -s.rdot_sign;
+        s.r_was_positive = false;
+        s.rdot_flips++;
+    } else if (rdotsq > 0) {
+        s.r_was_positive = true;
+    }
+    s.pr = fast_sqrt(__builtin_fabs(rdotsq)) * s.rdot_sign;
+    aux.rhosq = rhosq; aux.sin2theta = s2; aux.inv_rhosq = inv_rho;
+    return false;
+}
+
+// one derivative evaluation on either path
+template <typename T, bool FAST>
+KR_DEV void eval(T& pt, T& pr, T& ptheta, T& pphi, const Lane<T>& s, T r, T theta, T a)
+{
+    if constexpr (FAST) momentum_fast(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r, theta, a);
+    else momentum(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r, theta, a);
+}
+
 // loop condition of the theta-limit overloads (raytracer.cpp:172, :799, :1362-1364) or of the
 // RayDestination overloads (:1080, :1674)
 template <typename T, bool USE_DEST>
@@ -234,18 +356,46 @@ KR_DEV bool crossed_equator(T before, T after)
 
 // One iteration of the Euler (raytracer.cpp:172-313) or RK4 (:799-943, :1080-1229) loop body.
 // Returns true when the ray has finished (break, or the loop condition no longer holds).
-template <typename T, bool RK4, bool USE_DEST>
+template <typename T, bool RK4, bool USE_DEST, bool FAST>
 KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
 {
     const T a = c.a;
     ++s.steps;
 
+    T step;
+    T pt1, pr1, ptheta1, pphi1;
+    if constexpr (FAST) {
+        FastAux aux;
+        if (k1_with_flips_fast(s, a, aux)) return !(s.steps < c.steplim);
+        pt1 = s.pt; pr1 = s.pr; ptheta1 = s.ptheta; pphi1 = s.pphi;
+        // same heuristic, quotients as products with Newton-refined reciprocals
+        const T inv_pr = fast_rcp(pr1), inv_pth = fast_rcp(ptheta1);
+        const T q_th = kr_abs(s.theta * inv_pth);
+        step = kr_abs((s.r - c.horizon) * inv_pr) * c.inv_precision;
+        if (step > q_th * c.inv_precision) step = q_th * c.inv_theta_precision;
+        if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
+            const T st = kr_abs(c.max_tstep * fast_rcp(pt1));
+            if (step > st) step = st;
+        }
+        if (c.max_phistep > 0) {
+            const T sp = kr_abs(c.max_phistep * fast_rcp(pphi1));
+            if (step > sp) step = sp;
+        }
+        if (step < KR_MIN_STEP) step = KR_MIN_STEP;
+        if (c.rlim > 0 && s.r + pr1 * step > c.rlim) step = kr_abs((c.rlim - s.r) * inv_pr);
+        if (!USE_DEST) {
+            if (c.thetalim > 0 && s.theta + ptheta1 * step > c.thetalim) step = kr_abs((c.thetalim - s.theta) * inv_pth);
+        }
+        if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
+        const T two_r_rho = 2 * s.r * aux.inv_rhosq;
+        if ((1 - two_r_rho) * pt1 + (two_r_rho * a * aux.sin2theta) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
+    } else {
     T rhosq, sin2theta;
     if (k1_with_flips<T, false>(s, a, rhosq, sin2theta)) return !(s.steps < c.steplim);   // r, theta unchanged
-    const T pt1 = s.pt, pr1 = s.pr, ptheta1 = s.ptheta, pphi1 = s.pphi;
+    pt1 = s.pt; pr1 = s.pr; ptheta1 = s.ptheta; pphi1 = s.pphi;
 
     // step-size heuristic (:224-243 / :855-871 / :1136-1151)
-    T step = kr_abs((s.r - c.horizon) / pr1) / c.precision;
+    step = kr_abs((s.r - c.horizon) / pr1) / c.precision;
     if (step > kr_abs(s.theta / ptheta1) / c.precision) step = kr_abs(s.theta / ptheta1) / c.theta_precision;
     if (c.max_tstep > 0 && s.r < c.maxtstep_rlim && step > kr_abs(c.max_tstep / pt1)) step = kr_abs(c.max_tstep / pt1);
     if (c.max_phistep > 0 && step > kr_abs(c.max_phistep / pphi1)) step = kr_abs(c.max_phistep / pphi1);
@@ -258,6 +408,7 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     // flags (:264-273 / :874-887); neither ends the ray
     if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
     if ((1 - 2 * s.r / rhosq) * pt1 + (2 * a * s.r * sin2theta / rhosq) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
+    }
 
     const T theta_prev = s.theta;
     if (!RK4) {
@@ -268,20 +419,17 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     } else {
         // k2..k4 use k1's signs and move only (r, theta)  (:889-905)
         T pt2, pr2, ptheta2, pphi2;
-        momentum(pt2, pr2, ptheta2, pphi2, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, s.r + (step / 2) * pr1,
-                 s.theta + (step / 2) * ptheta1, a);
+        eval<T, FAST>(pt2, pr2, ptheta2, pphi2, s, s.r + (step / 2) * pr1, s.theta + (step / 2) * ptheta1, a);
         T acc_t = pt1 + 2 * pt2, acc_phi = pphi1 + 2 * pphi2;
         T pt3, pr3, ptheta3, pphi3;
-        momentum(pt3, pr3, ptheta3, pphi3, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, s.r + (step / 2) * pr2,
-                 s.theta + (step / 2) * ptheta2, a);
+        eval<T, FAST>(pt3, pr3, ptheta3, pphi3, s, s.r + (step / 2) * pr2, s.theta + (step / 2) * ptheta2, a);
         acc_t = acc_t + 2 * pt3;
         acc_phi = acc_phi + 2 * pphi3;
         T acc_r = pr1 + 2 * pr2 + 2 * pr3, acc_theta = ptheta1 + 2 * ptheta2 + 2 * ptheta3;
         T pt4, pr4, ptheta4, pphi4;
-        momentum(pt4, pr4, ptheta4, pphi4, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, s.r + step * pr3,
-                 s.theta + step * ptheta3, a);
+        eval<T, FAST>(pt4, pr4, ptheta4, pphi4, s, s.r + step * pr3, s.theta + step * ptheta3, a);
         // x += (step/6)(k1 + 2k2 + 2k3 + k4), summed left to right as in :908-912
-        const T w = step / 6;
+        const T w = FAST ? step * T(1.0 / 6.0) : step / 6;
         s.t += w * (acc_t + pt4);
         s.r += w * (acc_r + pr4);
         s.theta += w * (acc_theta + ptheta4);
@@ -342,7 +490,7 @@ KR_DEV void rk45_seed(Lane<T>& s, const TraceConsts<T>& c)
 // the outer step (:1438-1541); here a rejected lane keeps its k1 (s.pt..s.pphi hold k1 until a trial is
 // accepted) and retries on the next iteration, so a rejection never stalls the other 63 lanes.
 // attempts/rejects are per-lane counters.  Returns true when the ray has finished.
-template <typename T, bool USE_DEST>
+template <typename T, bool USE_DEST, bool FAST>
 KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& rejects, uint32_t& stationary_steps)
 {
     using D = Dopri<T>;
@@ -356,13 +504,30 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
 
     if (!s.in_retry) {
         ++s.steps;
+        T step_max;
+        if constexpr (FAST) {
+            FastAux aux;
+            if (k1_with_flips_fast(s, a, aux)) return !(s.steps < c.steplim);
+            if (s.pt <= 0) s.status |= KR_STATUS_ERGO;
+            const T two_r_rho = 2 * s.r * aux.inv_rhosq;
+            if ((1 - two_r_rho) * s.pt + (two_r_rho * a * aux.sin2theta) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
+            step_max = kr_abs((s.r - c.horizon) * fast_rcp(s.pr)) * c.inv_precision;
+            if (c.max_phistep > 0) {
+                const T step_phi = kr_abs(c.max_phistep * fast_rcp(s.pphi));
+                if (step_phi < step_max) step_max = step_phi;
+            }
+            if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
+                const T step_t = kr_abs(c.max_tstep * fast_rcp(s.pt));
+                if (step_t < step_max) step_max = step_t;
+            }
+        } else {
         T rhosq, sin2theta;
         if (k1_with_flips<T, true>(s, a, rhosq, sin2theta)) return !(s.steps < c.steplim);
         // flags (:1403-1410): same rhosq / sin2theta values as k1's
         if (s.pt <= 0) s.status |= KR_STATUS_ERGO;
         if ((1 - 2 * s.r / rhosq) * s.pt + (2 * a * s.r * sin2theta / rhosq) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
         // outer cap (:1421-1434): horizon / phi / t, no MIN_STEP floor afterwards
-        T step_max = kr_abs((s.r - c.horizon) / s.pr) / c.precision;
+        step_max = kr_abs((s.r - c.horizon) / s.pr) / c.precision;
         if (c.max_phistep > 0) {
             const T step_phi = kr_abs(c.max_phistep / s.pphi);
             if (step_phi < step_max) step_max = step_phi;
@@ -370,6 +535,7 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
         if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
             const T step_t = kr_abs(c.max_tstep / s.pt);
             if (step_t < step_max) step_max = step_t;
+        }
         }
         if (s.step > step_max) s.step = step_max;
         s.theta_prev = s.theta;
@@ -398,10 +564,10 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T pr2, ptheta2, pr3, ptheta3, pr4, ptheta4, pr5, ptheta5, pr6, ptheta6;
     T sum_t = D::b1 * pt1, sum_phi = D::b1 * pphi1;
 
-    momentum(pt_i, pr2, ptheta2, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r + h_try * D::a21 * pr1,
+    eval<T, FAST>(pt_i, pr2, ptheta2, pphi_i, s, r + h_try * D::a21 * pr1,
              theta + h_try * D::a21 * ptheta1, a);
 
-    momentum(pt_i, pr3, ptheta3, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
+    eval<T, FAST>(pt_i, pr3, ptheta3, pphi_i, s, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
              theta + h_try * (D::a31 * ptheta1 + D::a32 * ptheta2), a);
     sum_t = sum_t + D::b3 * pt_i;
     sum_phi = sum_phi + D::b3 * pphi_i;
@@ -433,7 +599,7 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     reflect_poles(theta_new, phi_new, s.thetadot_sign);
 
     T pt7, pr7, ptheta7, pphi7;
-    momentum(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a);
+    eval<T, FAST>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
 
     // error norm over (r, theta) and the step controller (:1508-1519)
     const T err_r = h_try * (D::e1 * pr1 + D::e3 * pr3 + D::e4 * pr4 + D::e5 * pr5 + D::e6 * pr6 + D::e7 * pr7);

@@ -170,10 +170,11 @@ __global__ void __launch_bounds__(kBlock) calculate_momentum_kernel(kr_ray_f64* 
 //      (pointsource.cpp:30-64) + calculate_constants (raytracer.cpp:625-676).  Fields the reference leaves
 //      indeterminate are zeroed. ------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, int n_cosalpha, int n_beta)
+pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, int n_cosalpha, int n_beta, long long first, long long stride)
 {
     const long long n_grid = (long long) n_cosalpha * n_beta;
-    for (long long ix = blockIdx.x * (long long) kBlock + threadIdx.x; ix < n; ix += (long long) gridDim.x * kBlock) {
+    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
+        const long long ix = first + slot * stride;       // index in the source's own ray array
         kr_ray_f64 ray;
         memset(&ray, 0, sizeof(ray));
         ray.steps = -1;
@@ -223,18 +224,19 @@ pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsour
                 ray.thetadot_sign = (thetadot > 0) ? 1 : -1;
             }
         }
-        rays[ix] = ray;
+        rays[slot] = ray;
     }
 }
 
 // ---- ImagePlane ctor + init_image_plane (imageplane.cpp:11-121) ---------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny)
+imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny, long long first, long long stride)
 {
     const long long n_grid = (long long) Nx * Ny;
     const double a = -1 * s.spin;                       // imageplane.cpp:12
     const double D = s.dist, incl = s.inc_deg * kPi / 180, phi0 = s.phi0;
-    for (long long ix = blockIdx.x * (long long) kBlock + threadIdx.x; ix < n; ix += (long long) gridDim.x * kBlock) {
+    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
+        const long long ix = first + slot * stride;
         kr_ray_f64 ray;
         memset(&ray, 0, sizeof(ray));
         ray.steps = -1;
@@ -284,7 +286,7 @@ imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane
             ray.alpha = x;
             ray.beta = y;
         }
-        rays[ix] = ray;
+        rays[slot] = ray;
     }
 }
 
@@ -416,24 +418,26 @@ int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st)
     return KR_OK;
 }
 
-int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, hipStream_t st)
+int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st)
 {
     int32_t nc = 0, nb = 0;
-    const int64_t need = kr_pointsource_count(s, &nc, &nb);
-    if (n < need) { set_error("kr_pointsource_init: n smaller than kr_pointsource_count()"); return KR_EINVAL; }
+    const int64_t total = kr_pointsource_count(s, &nc, &nb);
+    if (first < 0 || stride < 1) { set_error("kr_pointsource_init: bad first/stride"); return KR_EINVAL; }
+    if (first == 0 && stride == 1 && n < total) { set_error("kr_pointsource_init: n smaller than kr_pointsource_count()"); return KR_EINVAL; }
     if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(pointsource_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nc, nb);
+    hipLaunchKernelGGL(pointsource_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nc, nb, (long long) first, (long long) stride);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }
 
-int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, hipStream_t st)
+int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st)
 {
     int32_t nx = 0, ny = 0;
-    const int64_t need = kr_imageplane_count(s, &nx, &ny);
-    if (n < need) { set_error("kr_imageplane_init: n smaller than kr_imageplane_count()"); return KR_EINVAL; }
+    const int64_t total = kr_imageplane_count(s, &nx, &ny);
+    if (first < 0 || stride < 1) { set_error("kr_imageplane_init: bad first/stride"); return KR_EINVAL; }
+    if (first == 0 && stride == 1 && n < total) { set_error("kr_imageplane_init: n smaller than kr_imageplane_count()"); return KR_EINVAL; }
     if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(imageplane_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nx, ny);
+    hipLaunchKernelGGL(imageplane_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nx, ny, (long long) first, (long long) stride);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }

@@ -19,8 +19,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "kr_common.hpp"
 #include "kr_device.hpp"
@@ -38,6 +40,9 @@ constexpr int kBlock = 256;          // 4 independent waves per workgroup, no ba
 #endif
 #ifndef KR_LONG_RAY_PRIO
 #define KR_LONG_RAY_PRIO 1
+#endif
+#ifndef KR_GRADED_PRIO
+#define KR_GRADED_PRIO 1
 #endif
 #ifndef KR_LONG_RAY_STEPS
 #define KR_LONG_RAY_STEPS 2048
@@ -102,7 +107,7 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 // ---- the persistent kernel ------------------------------------------------------------------------
 // METHOD: KR_EULER / KR_RK4 / KR_RK45.  REFILL_MIN: a wave goes back to the queue when at least this many of its
 // lanes are free (or when none holds a ray).
-template <typename T, int METHOD, bool USE_DEST, int REFILL_MIN>
+template <typename T, int METHOD, bool USE_DEST, bool FAST, int REFILL_MIN>
 __global__ void __launch_bounds__(kBlock, KR_MIN_WAVES)
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters)
 {
@@ -116,7 +121,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     unsigned long long my_steps = 0, my_traced = 0;
     uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0;
 #if KR_LONG_RAY_PRIO
-    bool has_prio = false;
+    int has_prio = 0;
 #endif
 
     for (;;) {
@@ -165,19 +170,31 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
         // given issue priority over its SIMD neighbours so that the critical path runs at single-wave speed
         // instead of at 1/(waves per SIMD) of it.  Wave-uniform, re-evaluated only when the ballot changes.
         {
-            const bool want_prio = __any(have && s.steps > KR_LONG_RAY_STEPS);
+            // graded: the longer the wave's oldest ray, the higher its priority (0..3), so the rays that define the
+            // critical path do not have to share their priority level with the many merely "longish" ones
+            const int32_t st = have ? s.steps : 0;
+#if KR_GRADED_PRIO
+            const int want_prio = __any(st > 8 * KR_LONG_RAY_STEPS) ? 3 : __any(st > 3 * KR_LONG_RAY_STEPS) ? 2 : __any(st > KR_LONG_RAY_STEPS) ? 1 : 0;
+#else
+            const int want_prio = __any(st > KR_LONG_RAY_STEPS) ? 3 : 0;
+#endif
             if (want_prio != has_prio) {
                 has_prio = want_prio;
-                if (want_prio) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+                switch (want_prio) {
+                    case 3: __builtin_amdgcn_s_setprio(3); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    default: __builtin_amdgcn_s_setprio(0); break;
+                }
             }
         }
 #endif
 
         if (have) {
             bool fin;
-            if (METHOD == KR_EULER) fin = step_fixed<T, false, USE_DEST>(s, c);
-            else if (METHOD == KR_RK4) fin = step_fixed<T, true, USE_DEST>(s, c);
-            else fin = step_rk45<T, USE_DEST>(s, c, my_attempts, my_rejects, my_stationary);
+            if (METHOD == KR_EULER) fin = step_fixed<T, false, USE_DEST, FAST>(s, c);
+            else if (METHOD == KR_RK4) fin = step_fixed<T, true, USE_DEST, FAST>(s, c);
+            else fin = step_rk45<T, USE_DEST, FAST>(s, c, my_attempts, my_rejects, my_stationary);
             if (fin) {
                 my_steps += (unsigned long long) s.steps;
                 const int32_t out_steps = finish_status<T, USE_DEST>(s, c);
@@ -239,20 +256,32 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
     c.max_tstep = (T) p->max_tstep; c.maxtstep_rlim = (T) p->maxtstep_rlim; c.max_phistep = (T) p->max_phistep;
     c.tol = (T) p->rk45_tol;
     c.sp0 = (T) p->stop_params[0]; c.sp1 = (T) p->stop_params[1]; c.sp2 = (T) p->stop_params[2];
+    c.inv_precision = (T) (1.0 / p->precision);
+    c.inv_theta_precision = (T) (1.0 / p->theta_precision);
     c.steplim = steplim;
     c.stop_kind = p->stop_kind;
     return c;
 }
 
-template <typename T, int METHOD, bool USE_DEST>
+template <typename T, int METHOD, bool USE_DEST, bool FAST>
 int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, unsigned long long* counters, int cus,
-           hipStream_t stream)
+           hipStream_t stream, int max_blocks_per_cu)
 {
     constexpr int kRefill = KR_REFILL_MIN;
-    auto kern = trace_kernel<T, METHOD, USE_DEST, kRefill>;
+    auto kern = trace_kernel<T, METHOD, USE_DEST, FAST, kRefill>;
     int blocks_per_cu = 0;
     KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, kBlock, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
+    // Resident workgroups per CU (= waves per SIMD).  The launch ends with its longest ray, which advances one step
+    // per turn of its wave: with w waves per SIMD that turn comes round ~w times slower.  Measured on MI355X (RK4 f64):
+    // PointSource 1e7 rays (max 34 527 steps): 1 -> 233 ms, 2 -> 186 ms, 3 -> 208 ms; ImagePlane 4097^2 (max ~2 000
+    // steps): 1 -> 480, 2 -> 344, 3 -> 318 ms.  Default 2; kr_params.flags bits 8..11 or KR_BLOCKS_PER_CU override.
+    int want = max_blocks_per_cu > 0 ? max_blocks_per_cu : 2;
+    if (const char* e = getenv("KR_BLOCKS_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1) want = v;
+    }
+    if (want < blocks_per_cu) blocks_per_cu = want;
     const int64_t resident = (int64_t) cus * blocks_per_cu;
     const int64_t wanted = (n + kBlock - 1) / kBlock;
     const int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
@@ -268,14 +297,28 @@ int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned 
     R* rays = (R*) d_rays;
     const TraceConsts<T> c = make_consts<T>(p, steplim);
     const bool dest = (p->stop_kind != KR_STOP_THETA);
+    const int mb = KR_FLAG_GET_BLOCKS_PER_CU(p->flags);
+    if constexpr (std::is_same<T, double>::value) {
+        if (p->flags & KR_FLAG_FAST_MATH) {
+            switch (p->integrator) {
+                case KR_EULER: return launch<T, KR_EULER, false, true>(rays, n, c, counters, cus, stream, mb);
+                case KR_RK4:
+                    return dest ? launch<T, KR_RK4, true, true>(rays, n, c, counters, cus, stream, mb)
+                                : launch<T, KR_RK4, false, true>(rays, n, c, counters, cus, stream, mb);
+                default:
+                    return dest ? launch<T, KR_RK45, true, true>(rays, n, c, counters, cus, stream, mb)
+                                : launch<T, KR_RK45, false, true>(rays, n, c, counters, cus, stream, mb);
+            }
+        }
+    }
     switch (p->integrator) {
-        case KR_EULER: return launch<T, KR_EULER, false>(rays, n, c, counters, cus, stream);
+        case KR_EULER: return launch<T, KR_EULER, false, false>(rays, n, c, counters, cus, stream, mb);
         case KR_RK4:
-            return dest ? launch<T, KR_RK4, true>(rays, n, c, counters, cus, stream)
-                        : launch<T, KR_RK4, false>(rays, n, c, counters, cus, stream);
+            return dest ? launch<T, KR_RK4, true, false>(rays, n, c, counters, cus, stream, mb)
+                        : launch<T, KR_RK4, false, false>(rays, n, c, counters, cus, stream, mb);
         default:
-            return dest ? launch<T, KR_RK45, true>(rays, n, c, counters, cus, stream)
-                        : launch<T, KR_RK45, false>(rays, n, c, counters, cus, stream);
+            return dest ? launch<T, KR_RK45, true, false>(rays, n, c, counters, cus, stream, mb)
+                        : launch<T, KR_RK45, false, false>(rays, n, c, counters, cus, stream, mb);
     }
 }
 

@@ -38,6 +38,7 @@ n = first.kr_pointsource_count(C.byref(spec), None, None)
 d_rays = C.c_void_p()
 capi.check(first, first.kr_malloc(C.byref(d_rays), n * 144), "malloc")
 p = capi.default_params(bench.SPIN); p.integrator, p.r_max = method, bench.R_MAX
+p.flags = int(os.environ.get("KR_FLAGS", "0"))
 times = {t: [] for t, _ in specs}; steps = {}
 for rnd in range(a.rounds + 1):
     for tag, _ in specs:

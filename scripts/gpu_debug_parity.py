@@ -7,12 +7,13 @@ import golden_cases as gc, parity
 from raytrace_cpu_amd import api, capi
 from test_gpu_parity import hip_pipeline
 
+FLAGS = int(os.environ.get("KR_FLAGS", "0"))
 only = sys.argv[1:]
 for cname, case in gc.cases().items():
     g = np.load(gc.golden_path(cname))
     for run, params in case["runs"].items():
         if only and f"{cname}/{run}" not in only: continue
-        out, st = hip_pipeline(case, params, g["init"])
+        out, st = hip_pipeline(case, params, g["init"], FLAGS)
         want = g[f"final__{run}"]
         res = parity.compare_rays(out, want, rtol=parity.rtol_for(params), check_redshift=True)
         live = want["steps"] != -1

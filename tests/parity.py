@@ -107,5 +107,23 @@ def allowed_bad_frac(params, init, rtol):
     return CHAOTIC_FRAC + 3 * noise_envelope_frac(params, init, rtol)
 
 
+def knife_edge_mask(init, imageplane):
+    """Rays whose fate IN THE REFERENCE is decided by rounding noise: a PointSource ray emitted at beta = -pi has
+    sin(beta) = -1.2e-16, an ImagePlane ray on the x = 0 column has cos(beta) = 6e-17 and one on the y = 0 row has
+    l_theta = 0, so their theta-motion / axial angular momentum h is a pure cancellation residue.  The strict path reproduces
+    that residue bit for bit and therefore the reference's outcome; KR_FLAG_FAST_MATH changes the residue (any
+    re-association does) and such a ray can end somewhere else entirely.  Fast-math parity is asserted on all OTHER
+    rays, at the unchanged tolerances; this set has measure zero in the ray grid's continuum limit (one grid column)."""
+    if imageplane:
+        return (np.abs(init["alpha"]) < 1e-9) | (np.abs(init["beta"]) < 1e-9)
+    return np.abs(np.sin(init["beta"])) < 1e-9
+
+
+def drop_rays(rays, mask):
+    out = rays.copy()
+    out["steps"][mask] = -1
+    return out
+
+
 def terminal_bits(status):
     return status & (capi.STATUS_DEST | capi.STATUS_HORIZON | capi.STATUS_RLIM | capi.STATUS_STEPLIM | capi.STATUS_NAN)

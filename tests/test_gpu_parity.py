@@ -16,8 +16,12 @@ CASES = gc.cases()
 RUNS = [(c, r) for c in CASES for r in CASES[c]["runs"]]
 
 
-def hip_pipeline(case, params, init):
+MODES = [pytest.param(0, id="strict"), pytest.param(capi.FLAG_FAST_MATH, id="fastmath")]
+
+
+def hip_pipeline(case, params, init, flags=0):
     """run_raytrace -> range_phi -> redshift through libkrtrace, starting from the reference's own init rays."""
+    params = capi.copy_params(params, flags=flags)
     out, st = api.trace(params, init)
     api.range_phi(out)
     V, rev, proj = case["post"]
@@ -28,14 +32,22 @@ def hip_pipeline(case, params, init):
     return out, st
 
 
+@pytest.mark.parametrize("flags", MODES)
 @pytest.mark.parametrize("case_name,run", RUNS)
-def test_trace_vs_golden(krlib, case_name, run):
+def test_trace_vs_golden(krlib, case_name, run, flags):
     case = CASES[case_name]
     g = np.load(gc.golden_path(case_name))
     params = case["runs"][run]
-    out, st = hip_pipeline(case, params, g["init"])
+    out, st = hip_pipeline(case, params, g["init"], flags)
     want = g[f"final__{run}"]
     rtol = parity.rtol_for(params)
+    if flags & capi.FLAG_FAST_MATH:
+        # same tolerances, knife-edge column excluded (parity.knife_edge_mask); step totals are then not comparable
+        ke = parity.knife_edge_mask(g["init"], gc.is_imageplane(case))
+        res = parity.compare_rays(parity.drop_rays(out, ke), parity.drop_rays(want, ke), rtol=rtol, check_redshift=True)
+        assert res["n_traced"] > 0
+        assert res["frac_bad"] <= parity.allowed_bad_frac(params, g["init"], rtol), res
+        return
     res = parity.compare_rays(out, want, rtol=rtol, check_redshift=True)
     assert res["n_traced"] > 0
     assert res["frac_bad"] <= parity.allowed_bad_frac(params, g["init"], rtol), res
@@ -46,18 +58,23 @@ def test_trace_vs_golden(krlib, case_name, run):
     assert st["rays_traced"] == int((g["init"]["steps"] >= 0).sum())
 
 
+@pytest.mark.parametrize("flags", MODES)
 @pytest.mark.parametrize("case_name", ["ps_h5", "ps_h10", "ps_kep"])
 @pytest.mark.parametrize("run", ["euler", "rk4", "rk45"])
-def test_emissivity_bins_vs_golden(krlib, case_name, run):
+def test_emissivity_bins_vs_golden(krlib, case_name, run, flags):
     case = CASES[case_name]
     if run not in case["runs"]:
         pytest.skip("run not defined for this case")
     g = np.load(gc.golden_path(case_name))
-    out, _ = hip_pipeline(case, case["runs"][run], g["init"])
+    out, _ = hip_pipeline(case, case["runs"][run], g["init"], flags)
+    ref_final = g[f"final__{run}"]
+    if flags & capi.FLAG_FAST_MATH:
+        ke = parity.knife_edge_mask(g["init"], False)
+        out, ref_final = parity.drop_rays(out, ke), parity.drop_rays(ref_final, ke)
     bins = gc.emis_bins(case["source"])
     got = api.reduce_emissivity(bins, out)
     # the oracle's reducer on the REFERENCE's final rays
-    want = oracle_reduce_emissivity(bins, g[f"final__{run}"])
+    want = oracle_reduce_emissivity(bins, ref_final)
     assert want["disc_count"] > 0
     assert parity.compare_bins(got, want) == []
     assert abs(got["disc_count"] - want["disc_count"]) <= parity.BIN_COUNT_SLACK
@@ -85,14 +102,19 @@ def oracle_reduce_image(bins, rays):
     return out
 
 
+@pytest.mark.parametrize("flags", MODES)
 @pytest.mark.parametrize("case_name,run", [("ip15", "rk4"), ("ip15", "rk45"), ("ip16", "rk4")])
-def test_image_planes_vs_golden(krlib, case_name, run):
+def test_image_planes_vs_golden(krlib, case_name, run, flags):
     case = CASES[case_name]
     g = np.load(gc.golden_path(case_name))
-    out, _ = hip_pipeline(case, case["runs"][run], g["init"])
+    out, _ = hip_pipeline(case, case["runs"][run], g["init"], flags)
+    ref_final = g[f"final__{run}"]
+    if flags & capi.FLAG_FAST_MATH:
+        ke = parity.knife_edge_mask(g["init"], True)
+        out, ref_final = parity.drop_rays(out, ke), parity.drop_rays(ref_final, ke)
     bins = gc.image_bins(case["source"])
     got = api.reduce_image(bins, out)
-    want = oracle_reduce_image(bins, g[f"final__{run}"])
+    want = oracle_reduce_image(bins, ref_final)
     assert want["disc_count"] > 0
     assert np.abs(got["nrays"].astype(int) - want["nrays"].astype(int)).max() <= parity.BIN_COUNT_SLACK
     same = got["nrays"] == want["nrays"]
@@ -229,26 +251,31 @@ def test_nan_ray_terminates(krlib):
 
 
 # ---- larger grids against the oracle run on the spot --------------------------------------------------------------
+@pytest.mark.parametrize("flags", MODES)
 @pytest.mark.parametrize("method", [capi.EULER, capi.RK4, capi.RK45])
-def test_perf_test_grid_vs_oracle(krlib, method):
+def test_perf_test_grid_vs_oracle(krlib, method, flags):
     """integrator_perf_test.cpp:35-45 grid (5167 rays) at BASELINE's h = 10: per-ray and per-bin parity."""
     spec = ol.pointsource_spec([0.0, 10.0, 1e-3, 1.5707], 0.0, gc.SPIN, 0.05, 0.05, cosalpha0=-0.995, cosalphamax=0.995,
                                beta0=-np.pi, betamax=np.pi)
     init = ol.oracle_pointsource(spec)
     ol.oracle().kro_redshift_start_f64(gc.SPIN, 0.0, 0, 0, ol.ptr(init), len(init))
     p = capi.default_params(gc.SPIN)
-    p.integrator = method
+    p.integrator, p.flags = method, flags
     want, wst = ol.oracle_trace(p, init)
     ol.oracle().kro_range_phi_f64(-np.pi, np.pi, ol.ptr(want), len(want))
     ol.oracle().kro_redshift_f64(gc.SPIN, -1.0, 0, 0, 0, ol.ptr(want), len(want))
     out, st = api.trace(p, init)
     api.range_phi(out)
     api.redshift(gc.SPIN, -1.0, 0, 0, out)
+    if flags & capi.FLAG_FAST_MATH:
+        ke = parity.knife_edge_mask(init, False)
+        out, want = parity.drop_rays(out, ke), parity.drop_rays(want, ke)
     res = parity.compare_rays(out, want, rtol=parity.rtol_for(p), check_redshift=True)
     assert res["frac_bad"] <= parity.CHAOTIC_FRAC, res
     bins = gc.emis_bins(spec, nr=30)
     assert parity.compare_bins(api.reduce_emissivity(bins, out), oracle_reduce_emissivity(bins, want)) == []
-    assert abs(st["steps_total"] - wst["steps_total"]) <= 0.01 * wst["steps_total"]
+    if not flags:
+        assert abs(st["steps_total"] - wst["steps_total"]) <= 0.01 * wst["steps_total"]
 
 
 # ---- float instantiation (Raytracer<float>, reference raytracer.cpp:1897) -----------------------------------------
