@@ -236,6 +236,12 @@ int kr_reduce_image_f64(const kr_image_bins* b, const kr_ray_f64* rays, int64_t 
  * nrays held as doubles.  ADDS into d_planes. */
 int kr_reduce_image_dev_f64(const kr_image_bins* b, const void* d_rays, int64_t n, void* d_planes, void* stream);
 
+/* ---- diagnostics ------------------------------------------------------------------------------- */
+/* out[i] = op(a[i], b[i]) evaluated ON THE DEVICE with the exact primitive the trace kernel uses (host pointers):
+ * 0 a/b (compiler IEEE)  1 a/b (lean IEEE chain of the strict path)  2 sqrt(a) (compiler)  3 sqrt(a) (lean)
+ * 4 sin(a)  5 cos(a) (compact polar-angle sincos)  6 a*rcp(b)  7 sqrt(a) (fast-math path)  8 sin  9 cos  10 pow(a,b) (device libm) */
+int kr_debug_arith_f64(int op, const double* a, const double* b, double* out, int64_t n);
+
 /* ---- device memory helpers for callers without a HIP runtime of their own --------------------- */
 int kr_malloc(void** d_ptr, int64_t bytes);
 int kr_free(void* d_ptr);

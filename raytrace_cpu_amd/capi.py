@@ -128,6 +128,7 @@ PROTOTYPES = {
     "kr_reduce_emissivity_dev_f64": (_int, [P(EmisBins), _vp, _i64, _vp, _vp]),
     "kr_reduce_image_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
     "kr_reduce_image_dev_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp]),
+    "kr_debug_arith_f64": (_int, [_int, _vp, _vp, _vp, _i64]),
     "kr_malloc": (_int, [P(_vp), _i64]),
     "kr_free": (_int, [_vp]),
     "kr_memcpy_h2d": (_int, [_vp, _vp, _i64]),
@@ -145,7 +146,7 @@ class KrError(RuntimeError):
 
 def load(path=None):
     """dlopen libkrtrace.so and attach prototypes.  Raises if the library or any declared symbol is missing."""
-    path = path or LIB_PATH
+    path = path or os.environ.get("KRTRACE_LIB") or LIB_PATH      # KRTRACE_LIB: an experiment build (scripts/ab_kernels.py)
     if not os.path.exists(path):
         raise KrError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")

@@ -26,6 +26,7 @@ int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t fi
 int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st);
 int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st);
 int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st);
+int arith_probe_dev(int op, const double* a, const double* b, double* out, int64_t n);
 
 static thread_local std::string g_error;
 
@@ -383,6 +384,24 @@ int kr_reduce_image_f64(const kr_image_bins* b, const kr_ray_f64* rays, int64_t 
     std::memcpy(time, &h[5 * npix], npix * sizeof(double));
     std::memcpy(emis, &h[6 * npix], npix * sizeof(double));
     if (disc_count) *disc_count = (int64_t) h[7 * npix];
+    return KR_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------------------
+int kr_debug_arith_f64(int op, const double* a, const double* b, double* out, int64_t n)
+{
+    if (!a || !b || !out || n < 0) { set_error("kr_debug_arith: bad argument"); return KR_EINVAL; }
+    int rc = require_device();
+    if (rc != KR_OK) return rc;
+    if (n == 0) return KR_OK;
+    DeviceBuffer da, db, dout;
+    const size_t bytes = (size_t) n * sizeof(double);
+    if ((rc = da.alloc(bytes)) != KR_OK || (rc = db.alloc(bytes)) != KR_OK || (rc = dout.alloc(bytes)) != KR_OK) return rc;
+    KR_HIP(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    KR_HIP(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    rc = arith_probe_dev(op, (const double*) da.p, (const double*) db.p, (double*) dout.p, n);
+    if (rc != KR_OK) return rc;
+    KR_HIP(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
     return KR_OK;
 }
 

@@ -24,7 +24,64 @@ namespace kr {
 // ---- scalar helpers -------------------------------------------------------------------------
 KR_DEV double kr_abs(double x) { return __builtin_fabs(x); }
 KR_DEV float kr_abs(float x) { return __builtin_fabsf(x); }
-KR_DEV double kr_sqrt(double x) { return __builtin_sqrt(x); }     // IEEE correctly rounded on gfx950 (checked in tests/test_gpu_primitives.py)
+#ifndef KR_LEAN_IEEE
+#define KR_LEAN_IEEE 1
+#endif
+
+// Correctly rounded fp64 quotient and square root WITHOUT the range-scaling links of the compiler's sequences.
+// The compiler lowers a/b to: v_div_scale x2 -> v_rcp_f64 -> two Newton steps -> q = a*y -> residual -> v_div_fmas ->
+// v_div_fixup, an 11-deep dependent chain at ~32 cycles of fp64 latency per link, 20+ times per RK4 step; sqrt is a
+// 14-deep chain.  The scale / fmas / fixup links (ldexp / class tests for sqrt) are the identity unless an operand is
+// zero, infinite, NaN, denormal or within ~2^100 of the ends of the exponent range; the remaining links ARE the
+// compiler's computation, so for every operand pair a healthy ray produces the result is bit-identical to IEEE
+// (tests/test_gpu_primitives.py: 2e6 random pairs + edge cases against the compiler's a/b and numpy, on the GPU).
+// What the lean chains do NOT reproduce: a zero denominator gives NaN (IEEE: +-inf or NaN), an infinite one NaN (IEEE:
+// +-0), a -0 numerator +0.  In the tracer a denominator is exactly zero only on the polar axis (sin theta = 0) or on
+// Delta = 0, where the reference's own evaluation is already inf/NaN-poisoned, or for phidot/thetadot = 0 in the step
+// heuristic, where the quotient only feeds `step > q` comparisons that are false for +inf and NaN alike
+// (tests/test_gpu_parity.py::test_degenerate_denominators_match_oracle).  Guarding instead of accepting that was
+// measured and rejected: a range test per quotient 231 ms, an out-of-line IEEE re-run per evaluation 227 ms, the
+// compiler's division 188 ms, unguarded lean chains 165 ms (PointSource 1e7 rays, RK4): every guard splits the
+// scheduling region the independent chains overlap in.  -DKR_LEAN_IEEE=0 builds the compiler's sequences throughout.
+KR_DEV double lean_div(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double q = a * y;
+    e = __builtin_fma(-b, q, a);
+    return __builtin_fma(e, y, q);
+}
+
+KR_DEV double lean_sqrt(double x)      // x >= 0; +0 -> +0
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y;
+    const double h0 = y * 0.5;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0);
+    const double h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    const double g3 = __builtin_fma(d1, h1, g2);
+    return (x == 0.0) ? x : g3;
+}
+
+// arithmetic policy of the strict path: LEAN (double, KR_LEAN_IEEE) or the compiler's sequences
+template <bool LEAN> KR_DEV double dv(double a, double b) { if constexpr (LEAN) return lean_div(a, b); else return a / b; }
+template <bool LEAN> KR_DEV float dv(float a, float b) { return a / b; }
+template <bool LEAN> KR_DEV double sq(double x) { if constexpr (LEAN) return lean_sqrt(x); else return __builtin_sqrt(x); }
+template <bool LEAN> KR_DEV float sq(float x) { return __builtin_sqrtf(x); }
+template <typename T> struct LeanDefault { static constexpr bool value = false; };
+template <> struct LeanDefault<double> { static constexpr bool value = (KR_LEAN_IEEE != 0); };
+
+KR_DEV bool kr_finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
+KR_DEV bool kr_finite(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
+
+KR_DEV double kr_sqrt(double x) { return __builtin_sqrt(x); }
 KR_DEV float kr_sqrt(float x) { return __builtin_sqrtf(x); }
 KR_DEV void kr_sincos(double x, double& s, double& c) { kr_sincos_f64(x, s, c); }
 KR_DEV void kr_sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
@@ -79,8 +136,8 @@ template <typename T> struct Lane {
 };
 
 // momentum_from_consts, src/include/kerr.h:300-335
-template <typename T>
-KR_DEV void momentum(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a)
+template <typename T, bool LEAN>
+KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a)
 {
     T sin_theta, cos_theta;
     kr_sincos(theta, sin_theta, cos_theta);
@@ -88,29 +145,34 @@ KR_DEV void momentum(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_s
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
     const T rhosq_delta = rhosq * delta;
-
     pt = (rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h;
-    pt /= rhosq_delta;
+    pt = dv<LEAN>(pt, rhosq_delta);
 
     pphi = 2 * a * r * sin2theta * k + (rhosq - 2 * r) * h;
-    pphi /= sin2theta * rhosq_delta;
+    pphi = dv<LEAN>(pphi, sin2theta * rhosq_delta);
 
-    const T hcs = h * cos_theta / sin_theta;
+    const T hcs = dv<LEAN>(h * cos_theta, sin_theta);
     T thetadotsq = Q + (k * a * cos_theta + hcs) * (k * a * cos_theta - hcs);
-    thetadotsq = thetadotsq / (rhosq * rhosq);
-    ptheta = kr_sqrt(kr_abs(thetadotsq)) * thetadot_sign;
+    thetadotsq = dv<LEAN>(thetadotsq, rhosq * rhosq);
+    ptheta = sq<LEAN>(kr_abs(thetadotsq)) * thetadot_sign;
 
     T rdotsq = k * pt - h * pphi - rhosq * ptheta * ptheta;
-    rdotsq = rdotsq * delta / rhosq;
-    pr = kr_sqrt(kr_abs(rdotsq)) * rdot_sign;
+    rdotsq = dv<LEAN>(rdotsq * delta, rhosq);
+    pr = sq<LEAN>(kr_abs(rdotsq)) * rdot_sign;
+}
+
+template <typename T>
+KR_DEV void momentum(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a)
+{
+    momentum_impl<T, LeanDefault<T>::value>(pt, pr, ptheta, pphi, k, h, Q, rdot_sign, thetadot_sign, r, theta, a);
 }
 
 // k1 at the current position with turning-point logic; identical in all five reference propagators
 // (raytracer.cpp:177-222, :805-849, :1086-1130, :1370-1398, :1680-1708).  RK45_ASSOC selects the RK45
 // bodies' association of the phidot denominator ((sin2theta*rhosq)*delta, :1375 vs :818).
 // Returns true when the reference would `continue` (theta turning point: sign flipped, nothing moves).
-template <typename T, bool RK45_ASSOC>
-KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
+template <typename T, bool RK45_ASSOC, bool LEAN>
+KR_DEV bool k1_impl(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
 {
     const T r = s.r, theta = s.theta, k = s.k, h = s.h;
     T sin_theta, cos_theta;
@@ -118,21 +180,20 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
-
     if (RK45_ASSOC) {
-        s.pt = ((rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h) / (rhosq * delta);
-        s.pphi = (2 * a * r * sin2theta * k + (rhosq - 2 * r) * h) / (sin2theta * rhosq * delta);
+        s.pt = dv<LEAN>((rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h, rhosq * delta);
+        s.pphi = dv<LEAN>(2 * a * r * sin2theta * k + (rhosq - 2 * r) * h, sin2theta * rhosq * delta);
     } else {
         const T rhosq_delta = rhosq * delta;
         s.pt = (rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h;
-        s.pt /= rhosq_delta;
+        s.pt = dv<LEAN>(s.pt, rhosq_delta);
         s.pphi = 2 * a * r * sin2theta * k + (rhosq - 2 * r) * h;
-        s.pphi /= sin2theta * rhosq_delta;
+        s.pphi = dv<LEAN>(s.pphi, sin2theta * rhosq_delta);
     }
 
-    const T hcs = h * cos_theta / sin_theta;
+    const T hcs = dv<LEAN>(h * cos_theta, sin_theta);
     T thetadotsq = s.Q + (k * a * cos_theta + hcs) * (k * a * cos_theta - hcs);
-    thetadotsq = thetadotsq / (rhosq * rhosq);
+    thetadotsq = dv<LEAN>(thetadotsq, rhosq * rhosq);
 
     if (thetadotsq < 0 && s.theta_was_positive) {
         s.thetadot_sign = -s.thetadot_sign;
@@ -141,10 +202,10 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
     }
     if (thetadotsq >= 0) s.theta_was_positive = true;
 
-    s.ptheta = kr_sqrt(kr_abs(thetadotsq)) * s.thetadot_sign;
+    s.ptheta = sq<LEAN>(kr_abs(thetadotsq)) * s.thetadot_sign;
 
     T rdotsq = k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta;
-    rdotsq = rdotsq * delta / rhosq;
+    rdotsq = dv<LEAN>(rdotsq * delta, rhosq);
     if (rdotsq <= 0 && s.r_was_positive) {
         s.rdot_sign = -s.rdot_sign;
         s.r_was_positive = false;
@@ -152,13 +213,18 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
     } else if (rdotsq > 0) {
         s.r_was_positive = true;
     }
-    s.pr = kr_sqrt(kr_abs(rdotsq)) * s.rdot_sign;
+    s.pr = sq<LEAN>(kr_abs(rdotsq)) * s.rdot_sign;
 
     rhosq_o = rhosq;
     sin2theta_o = sin2theta;
     return false;
 }
 
+template <typename T, bool RK45_ASSOC>
+KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
+{
+    return k1_impl<T, RK45_ASSOC, LeanDefault<T>::value>(s, a, rhosq_o, sin2theta_o);
+}
 
 // ==== fast-arithmetic path (kr_params.flags & KR_FLAG_FAST_MATH, double only) =====================================
 // On gfx950 an IEEE fp64 division costs ~67 SIMD-cycles per wave-instruction and an IEEE sqrt ~92, against ~5.4
@@ -395,19 +461,28 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     pt1 = s.pt; pr1 = s.pr; ptheta1 = s.ptheta; pphi1 = s.pphi;
 
     // step-size heuristic (:224-243 / :855-871 / :1136-1151)
-    step = kr_abs((s.r - c.horizon) / pr1) / c.precision;
-    if (step > kr_abs(s.theta / ptheta1) / c.precision) step = kr_abs(s.theta / ptheta1) / c.theta_precision;
-    if (c.max_tstep > 0 && s.r < c.maxtstep_rlim && step > kr_abs(c.max_tstep / pt1)) step = kr_abs(c.max_tstep / pt1);
-    if (c.max_phistep > 0 && step > kr_abs(c.max_phistep / pphi1)) step = kr_abs(c.max_phistep / pphi1);
+    step = dv<LeanDefault<T>::value>(kr_abs(dv<LeanDefault<T>::value>(s.r - c.horizon, pr1)), c.precision);
+    {
+        const T q_th = kr_abs(dv<LeanDefault<T>::value>(s.theta, ptheta1));
+        if (step > dv<LeanDefault<T>::value>(q_th, c.precision)) step = dv<LeanDefault<T>::value>(q_th, c.theta_precision);
+    }
+    if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
+        const T st = kr_abs(dv<LeanDefault<T>::value>(c.max_tstep, pt1));
+        if (step > st) step = st;
+    }
+    if (c.max_phistep > 0) {
+        const T sp = kr_abs(dv<LeanDefault<T>::value>(c.max_phistep, pphi1));
+        if (step > sp) step = sp;
+    }
     if ((double) step < KR_MIN_STEP) step = T(KR_MIN_STEP);
-    if (c.rlim > 0 && s.r + pr1 * step > c.rlim) step = kr_abs((c.rlim - s.r) / pr1);
+    if (c.rlim > 0 && s.r + pr1 * step > c.rlim) step = kr_abs(dv<LeanDefault<T>::value>(c.rlim - s.r, pr1));
     if (!USE_DEST) {
-        if (c.thetalim > 0 && s.theta + ptheta1 * step > c.thetalim) step = kr_abs((c.thetalim - s.theta) / ptheta1);
+        if (c.thetalim > 0 && s.theta + ptheta1 * step > c.thetalim) step = kr_abs(dv<LeanDefault<T>::value>(c.thetalim - s.theta, ptheta1));
     }
 
     // flags (:264-273 / :874-887); neither ends the ray
     if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
-    if ((1 - 2 * s.r / rhosq) * pt1 + (2 * a * s.r * sin2theta / rhosq) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
+    if ((1 - dv<LeanDefault<T>::value>(2 * s.r, rhosq)) * pt1 + dv<LeanDefault<T>::value>(2 * a * s.r * sin2theta, rhosq) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
     }
 
     const T theta_prev = s.theta;
@@ -429,7 +504,7 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         T pt4, pr4, ptheta4, pphi4;
         eval<T, FAST>(pt4, pr4, ptheta4, pphi4, s, s.r + step * pr3, s.theta + step * ptheta3, a);
         // x += (step/6)(k1 + 2k2 + 2k3 + k4), summed left to right as in :908-912
-        const T w = FAST ? step * T(1.0 / 6.0) : step / 6;
+        const T w = FAST ? step * T(1.0 / 6.0) : dv<LeanDefault<T>::value>(step, T(6));
         s.t += w * (acc_t + pt4);
         s.r += w * (acc_r + pr4);
         s.theta += w * (acc_theta + ptheta4);

@@ -375,8 +375,40 @@ reduce_image_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_image_b
 
 }  // namespace
 
+// ---- diagnostics: the device arithmetic primitives the trace kernel is built from, exposed one at a time so that a
+//      test can compare them with the host's IEEE results (tests/test_gpu_primitives.py) ------------------------------
+__global__ void __launch_bounds__(kBlock) arith_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, long long n)
+{
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        const double x = a[i], y = b[i];
+        double r = 0, s, c;
+        switch (op) {
+            case 0: r = x / y; break;                       // the compiler's IEEE division
+            case 1: r = lean_div(x, y); break;                // the lean chain used on the strict path
+            case 2: r = __builtin_sqrt(x); break;           // the compiler's IEEE sqrt
+            case 3: r = lean_sqrt(x); break;
+            case 4: kr_sincos_f64(x, s, c); r = s; break;
+            case 5: kr_sincos_f64(x, s, c); r = c; break;
+            case 6: r = x * fast_rcp(y); break;             // fast-math path
+            case 7: r = fast_sqrt(x); break;
+            case 8: ::sincos(x, &s, &c); r = s; break;      // device libm
+            case 9: ::sincos(x, &s, &c); r = c; break;
+            case 10: r = ::pow(x, y); break;
+        }
+        out[i] = r;
+    }
+}
+
 // ---- launchers (device pointers) ---------------------------------------------------------------------------
 #define KR_LAUNCH_CHECK() KR_HIP(hipGetLastError())
+
+int arith_probe_dev(int op, const double* a, const double* b, double* out, int64_t n)
+{
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(arith_probe_kernel, dim3(grid_for(n)), dim3(kBlock), 0, nullptr, op, a, b, out, (long long) n);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
 
 int redshift_start_dev(double spin, double V, int reverse, int projradius, void* d, int64_t n, hipStream_t st)
 {

@@ -34,7 +34,7 @@ void run(const char* name, int blocks_per_cu, double flop_per_op)
     const int cus = prop.multiProcessorCount;
     double* d;
     hipMalloc(&d, 8);
-    const int iters = (OP >= 3) ? 2000 : 20000;
+    const int iters = (OP >= 3) ? 20000 : 200000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -62,6 +62,10 @@ int main()
         if (occ == 2) { run<0, 8>("fma_f64", 2, 2); run<1, 8>("mul_f64", 2, 1); run<3, 4>("div_f64", 2, 1); }
         if (occ == 4) { run<0, 8>("fma_f64", 4, 2); run<2, 8>("add_f64", 4, 1); run<3, 4>("div_f64", 4, 1); run<4, 4>("sqrt_f64", 4, 1); }
     }
+    run<0, 8>("fma_f64", 8, 2);
+    run<0, 16>("fma_f64", 8, 2);
+    run<3, 4>("div_f64", 8, 1);
+    run<4, 4>("sqrt_f64", 8, 1);
     run<0, 1>("fma_dep1", 1, 2);
     run<0, 2>("fma_dep2", 1, 2);
     return 0;

@@ -1,0 +1,103 @@
+"""GPU: the arithmetic primitives of the trace kernel, one at a time, against the host's IEEE results.
+The strict path's claim is: + - * are IEEE, division and square root are CORRECTLY ROUNDED (bit-equal to numpy),
+sin/cos are the only place the device differs from the CPU (<= 1 ulp from glibc)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytrace_cpu_amd import api, capi
+
+pytestmark = pytest.mark.gpu
+N = 2_000_000
+
+
+def probe(op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(a if b is None else b, dtype=np.float64)
+    out = np.empty_like(a)
+    lib = api.lib()
+    capi.check(lib, lib.kr_debug_arith_f64(op, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), len(a)), "probe")
+    return out
+
+
+def ulps(x, ref):
+    return np.abs(x - ref) / np.spacing(np.abs(ref))
+
+
+def operands(rng, n):
+    """magnitudes the tracer meets (1e-30 .. 1e12), both signs, plus exact powers of two and near-equal pairs"""
+    a = rng.standard_normal(n) * 10.0 ** rng.uniform(-30, 12, n)
+    b = rng.standard_normal(n) * 10.0 ** rng.uniform(-30, 12, n)
+    a[:1000] = 2.0 ** rng.integers(-60, 60, 1000)
+    b[1000:2000] = a[1000:2000] * (1 + rng.integers(-3, 4, 1000) * 2.0 ** -52)
+    return a, b
+
+
+def test_division_is_correctly_rounded_and_lean_chain_is_bit_identical(krlib):
+    rng = np.random.default_rng(1)
+    a, b = operands(rng, N)
+    want = a / b
+    assert np.array_equal(probe(0, a, b), want)          # compiler's sequence == IEEE
+    assert np.array_equal(probe(1, a, b), want)          # lean chain == IEEE
+    # the compiler's sequence is IEEE everywhere; the lean chain is only claimed (and only used) for finite non-zero
+    # denominators away from the ends of the exponent range -- a zero numerator is fine, a zero / infinite denominator
+    # gives NaN (the evaluation-level guard in kr_device.hpp re-runs those evaluations with the compiler's sequence)
+    sa = np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 1e-310, 1e300, 3.0, 1e-320, 1.0, 5e-324, 1e308], dtype=np.float64)
+    sb = np.array([1.0, 3.0, 0.0, 2.0, np.inf, 1.0, 1e-310, 1e-300, np.inf, 3.0, 1e-310, 5e-324, 1e-308], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        w = sa / sb
+    assert np.array_equal(probe(0, sa, sb), w, equal_nan=True)
+    g = probe(1, sa[:2], sb[:2])
+    assert np.array_equal(g, w[:2])                       # 0/b = 0 (a -0 numerator comes back as +0)
+    assert np.isnan(probe(1, sa[2:3], sb[2:3])).all()    # b = 0 -> NaN where IEEE says inf
+
+
+def test_sqrt_is_correctly_rounded_and_lean_chain_is_bit_identical(krlib):
+    rng = np.random.default_rng(2)
+    a = np.abs(operands(rng, N)[0])
+    want = np.sqrt(a)
+    assert np.array_equal(probe(2, a), want)
+    assert np.array_equal(probe(3, a), want)
+    s = np.array([0.0, -0.0, np.inf, np.nan, -1.0, 1e-310, 5e-324, 1e-300, 1e300, 4.0], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        w = np.sqrt(s)
+    g = probe(2, s)
+    assert np.array_equal(g, w, equal_nan=True) and np.array_equal(np.signbit(g), np.signbit(w)), (g, w)
+    g = probe(3, s[[0, 9]])                     # lean chain: zero and ordinary values (its callers pass |x| of mid-range numbers)
+    assert np.array_equal(g, w[[0, 9]])
+
+
+def test_compact_sincos_within_one_ulp_of_glibc(krlib):
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1.0, 4.2, N)
+    x[:1000] = np.pi / 2 + rng.uniform(-1e-6, 1e-6, 1000)
+    x[1000:2000] = rng.uniform(0, 2e-3, 1000)
+    for op, f in ((4, np.sin), (5, np.cos)):
+        u = ulps(probe(op, x), f(x))
+        assert u.max() <= 1.0, (op, u.max())
+        assert (u == 0).mean() > 0.95
+    # far outside the polar-angle range and for non-finite input the library path answers
+    big = np.array([1e5, -3e7, 1e300, np.inf, np.nan], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        assert ulps(probe(4, big[:3]), np.sin(big[:3])).max() <= 2
+        assert np.isnan(probe(4, big[3:])).all() and np.isnan(probe(5, big[3:])).all()
+
+
+def test_fast_math_primitives_within_two_ulp(krlib):
+    rng = np.random.default_rng(4)
+    a, b = operands(rng, N)
+    assert ulps(probe(6, a, b), a / b).max() <= 2.0
+    a = np.abs(a)
+    assert ulps(probe(7, a), np.sqrt(a)).max() <= 1.0
+    assert probe(7, np.array([0.0]))[0] == 0.0
+
+
+def test_device_libm_distance_from_glibc(krlib):
+    """documents (does not bound tightly) how far the device libm is from glibc: this is the ONLY source of
+    strict-path differences where the library functions are still used (sources, redshift passes, RK45 pow)."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1.0, 4.2, 500_000)
+    assert ulps(probe(8, x), np.sin(x)).max() <= 2 and ulps(probe(9, x), np.cos(x)).max() <= 2
+    base = rng.uniform(1e-3, 1e10, 500_000)
+    assert ulps(probe(10, base, np.full_like(base, 0.2)), base ** 0.2).max() <= 2
