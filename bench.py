@@ -224,6 +224,7 @@ def main():
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
     ap.add_argument("--fast-math", action="store_true", help="KR_FLAG_FAST_MATH (opt-in; see include/kr_trace.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-math-extra", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=float, default=0)
     args = ap.parse_args()
 
@@ -290,6 +291,20 @@ def main():
         traced_all, steps_all = traced, steps_total
 
     h = res.cpu().numpy()
+    # the opt-in KR_FLAG_FAST_MATH path on the same workload, reported beside the headline (never AS the headline)
+    fast_extra = None
+    if world == 1 and not args.fast_math and not args.no_fast_math_extra:
+        wl.p.flags |= capi.FLAG_FAST_MATH
+        one_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fst = [one_step() for _ in range(2)]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 2
+        wl.p.flags &= ~capi.FLAG_FAST_MATH
+        fast_extra = {"value": fst[-1]["rays_traced"] / dt, "unit": "rays/s", "rk_steps_per_sec": fst[-1]["steps_total"] / dt,
+                      "avg_kernel_ms": float(np.mean([x["kernel_ms"] for x in fst])), "ms_per_step": 1e3 * dt,
+                      "note": "kr_params.flags |= KR_FLAG_FAST_MATH: shared reciprocals, Newton rcp/rsq, FMA; same tolerances except knife-edge rays (DESIGN.md)"}
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
@@ -321,6 +336,8 @@ def main():
                          "note": "latency-bound scalar fp64 ODE: neither HBM nor MFMA bounds it (SURVEY.md 8d); priced against vector fp64 peak"},
         }
         out.update(wl.summary(h))
+        if fast_extra is not None:
+            out["fast_math_opt_in"] = fast_extra
         if args.integrator == "rk45":
             out["rk45"] = {k: int(stats_last[k]) for k in ("rk45_attempts", "rk45_rejects", "rk45_stationary_steps")}
         if not args.no_cpu_baseline and args.workload == "emissivity":

@@ -273,10 +273,13 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, kBlock, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     // Resident workgroups per CU (= waves per SIMD).  The launch ends with its longest ray, which advances one step
-    // per turn of its wave: with w waves per SIMD that turn comes round ~w times slower.  Measured on MI355X (RK4 f64):
-    // PointSource 1e7 rays (max 34 527 steps): 1 -> 233 ms, 2 -> 186 ms, 3 -> 208 ms; ImagePlane 4097^2 (max ~2 000
-    // steps): 1 -> 480, 2 -> 344, 3 -> 318 ms.  Default 2; kr_params.flags bits 8..11 or KR_BLOCKS_PER_CU override.
-    int want = max_blocks_per_cu > 0 ? max_blocks_per_cu : 2;
+    // per turn of its wave: with w waves per SIMD that turn comes round ~w times slower, while throughput keeps
+    // improving up to ~3 waves.  Measured on MI355X, RK4 f64 strict, kernel ms at 1 / 2 / 3 workgroups per CU:
+    //   PointSource 1e7 rays (longest ray 34 527 steps)  211 / 165 / 183      PointSource 3e7 rays   - / 455 / 432
+    //   ImagePlane 4097^2 rays (longest ~2 000 steps)     480 / 344 / 318      fast-math 1e7 rays   176 / 121 / 110
+    // Default: 3 when the launch is long enough for throughput to dominate (n >= 2e7, or fast-math with n >= 5e6),
+    // else 2.  kr_params.flags bits 8..11 (KR_FLAG_BLOCKS_PER_CU) or the KR_BLOCKS_PER_CU environment variable override.
+    int want = max_blocks_per_cu > 0 ? max_blocks_per_cu : ((n >= 20000000 || (FAST && n >= 5000000)) ? 3 : 2);
     if (const char* e = getenv("KR_BLOCKS_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1) want = v;
