@@ -214,12 +214,74 @@ class ImagePlaneWorkload:
         return {"disc_hits": float(h[-1]), "lit_pixels": int((h[: self.N * self.N] > 0).sum())}
 
 
+class ReturnRadiationWorkload:
+    """BASELINE configs[4]: disc -> disc returning radiation.  Nr source radii log-spaced r_isco .. 500 on the disc (theta = pi/2 - 1e-6,
+    Keplerian V), ~1e6 rays each over beta in [0, pi), Euler to 1.1 r_esc (disc_source_photonfrac_r.cpp:74-135), one relaunch per
+    radius, escape/return/lost weighted fractions per radius.  Radii are sharded across ranks; the Nr x 4 table is all-reduced."""
+    name = "return_radiation"
+
+    def __init__(self, args, lib, capi, api, rank, world):
+        self.lib, self.capi, self.api = lib, capi, api
+        self.method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[args.integrator]
+        self.nr = args.radii
+        rays = args.rays or 1e6
+        self.r_isco = lib.kr_kerr_isco(SPIN, 1)
+        dr = math.exp(math.log(R_DISC / self.r_isco) / self.nr)
+        self.radii = [(ir, self.r_isco * dr ** ir) for ir in range(self.nr) if ir % world == rank]
+        d = 1.99 / (math.sqrt(rays) - 1.0)
+        self.specs = []
+        for ir, r_s in self.radii:
+            s = capi.PointSourceSpec()
+            for i, v in enumerate([0.0, r_s, math.pi / 2 - 1e-6, 1.5707]):
+                s.pos[i] = v
+            s.V, s.spin, s.tol, s.E = lib.kr_disc_velocity(r_s, SPIN, 1), SPIN, 100.0, 1.0
+            s.cosalpha0, s.cosalphamax, s.dcosalpha = -0.995, 0.995, d
+            s.beta0, s.betamax, s.dbeta = 0.0, math.pi, d * (math.pi / 2) / 0.995
+            self.specs.append(s)
+        self.n = max(api.pointsource_count(s)[0] for s in self.specs)
+        self.p = capi.default_params(SPIN)
+        self.p.integrator, self.p.r_max = self.method, 1.1 * R_MAX
+        self.result_words = 4 * self.nr
+        self.describe = (f"disc->disc returning radiation: {self.nr} source radii r_isco..500 x ~{int(rays)} rays (beta in [0,pi)), {args.integrator.upper()}, "
+                         f"r_max=1.1*r_esc, per-radius relaunch (BASELINE configs[4])")
+        self.pipeline = "per radius: pointsource_init+redshift_start+trace+range_phi+return_classification"
+        self.sharding = f"radii cyclic over {world} rank(s)"
+
+    def step(self, d_rays, d_res, stream):
+        lib, capi, vp = self.lib, self.capi, C.c_void_p
+        tot = None
+        for (ir, r_s), s in zip(self.radii, self.specs):
+            n = self.api.pointsource_count(s)[0]
+            capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(s), vp(d_rays), n, vp(stream)), "init")
+            capi.check(lib, lib.kr_redshift_start_dev_f64(SPIN, s.V, 0, 0, vp(d_rays), n, vp(stream)), "redshift_start")
+            st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
+            capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(d_rays), n, vp(stream)), "range_phi")
+            b = capi.ReturnBins()
+            b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, r_s, 1.5707
+            b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
+            capi.check(lib, lib.kr_reduce_return_dev_f64(C.byref(b), vp(d_rays), n, vp(d_res + 32 * ir), vp(stream)), "reduce")
+            if tot is None:
+                tot = dict(st)
+            else:
+                for k in ("rays_traced", "steps_total", "rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "kernel_ms"):
+                    tot[k] += st[k]
+        return tot
+
+    def summary(self, h):
+        t = h.reshape(self.nr, 4)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            f = t[:, 1:] / t[:, :1]
+        pick = [0, self.nr // 4, self.nr // 2, self.nr - 1]
+        return {"fractions_escape_return_lost": {f"radius_index_{i}": [float(f[i, 1]), float(f[i, 0]), float(f[i, 2])] for i in pick}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="emissivity", choices=["emissivity", "imageplane"])
+    ap.add_argument("--workload", default="emissivity", choices=["emissivity", "imageplane", "return_radiation"])
+    ap.add_argument("--radii", type=int, default=100, help="return_radiation: number of source radii")
     ap.add_argument("--rays", type=float, default=0, help="rays per GPU (default: 1e7 emissivity = BASELINE configs[1]; 4097^2 imageplane = configs[3])")
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
     ap.add_argument("--fast-math", action="store_true", help="KR_FLAG_FAST_MATH (opt-in; see include/kr_trace.h)")
@@ -248,7 +310,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    wl = (EmissivityWorkload if args.workload == "emissivity" else ImagePlaneWorkload)(args, lib, capi, api, rank, world)
+    if args.workload == "return_radiation" and args.integrator == "rk4" and "--integrator" not in " ".join(sys.argv):
+        args.integrator = "euler"         # the reference driver uses the Euler integrator (disc_source_photonfrac_r.cpp:92)
+    wl = {"emissivity": EmissivityWorkload, "imageplane": ImagePlaneWorkload, "return_radiation": ReturnRadiationWorkload}[args.workload](args, lib, capi, api, rank, world)
     if args.fast_math:
         wl.p.flags |= capi.FLAG_FAST_MATH
     n = wl.n
@@ -342,7 +406,7 @@ def main():
             out["rk45"] = {k: int(stats_last[k]) for k in ("rk45_attempts", "rk45_rejects", "rk45_stationary_steps")}
         if not args.no_cpu_baseline and args.workload == "emissivity":
             out["cpu_baseline"] = cpu_baseline(args, capi, api, wl.method, wl.d)
-        elif not args.no_cpu_baseline:
+        elif not args.no_cpu_baseline and args.workload == "imageplane":
             out["cpu_baseline"] = cpu_baseline_imageplane(args, capi, api, wl)
         print(json.dumps(out), flush=True)
     if dist is not None:

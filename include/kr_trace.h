@@ -171,6 +171,18 @@ typedef struct kr_image_bins {
     int32_t pad;
 } kr_image_bins;
 
+/* disc -> disc returning-radiation classification, src/return_radiation/disc_source_photonfrac_r.cpp:97-126
+ * (that app is stale in the reference -- it calls accessors that no longer exist -- so this follows its loop body
+ * against the live Ray<T> fields: cos(alpha) is rays[].alpha, beta is rays[].beta) */
+typedef struct kr_return_bins {
+    double r_isco, r_disc, r_esc;
+    double source_r, source_phi;
+    int32_t plane_iso;       /* weight = |sin(alpha) sin(beta)| instead of 1 */
+    int32_t limb;            /* weight *= 1 + 2.06 |sin(alpha) sin(beta)| */
+    int32_t weight_norm;     /* ray_count accumulates the weight instead of 1 */
+    int32_t pad;
+} kr_return_bins;
+
 /* ---- runtime ---------------------------------------------------------------------------------- */
 int         kr_abi_version(void);
 const char* kr_last_error(void);
@@ -235,6 +247,11 @@ int kr_reduce_image_f64(const kr_image_bins* b, const kr_ray_f64* rays, int64_t 
 /* d_planes: device buffer of 7*img_nx*img_ny+1 doubles [nrays | flux | r | phi | enshift | time | emis | disc_count],
  * nrays held as doubles.  ADDS into d_planes. */
 int kr_reduce_image_dev_f64(const kr_image_bins* b, const void* d_rays, int64_t n, void* d_planes, void* stream);
+
+/* disc_source_photonfrac_r.cpp:97-126: out[4] = {ray_count, return_count, escape_count, lost_count} (weighted sums);
+ * the app's three fractions are out[1..3] / out[0].  _dev ADDS into d_out4 (4 doubles, zero first). */
+int kr_reduce_return_f64(const kr_return_bins* b, const kr_ray_f64* rays, int64_t n, double out[4]);
+int kr_reduce_return_dev_f64(const kr_return_bins* b, const void* d_rays, int64_t n, void* d_out4, void* stream);
 
 /* ---- diagnostics ------------------------------------------------------------------------------- */
 /* out[i] = op(a[i], b[i]) evaluated ON THE DEVICE with the exact primitive the trace kernel uses (host pointers):

@@ -896,6 +896,32 @@ void kro_reduce_image_f64(const kr_image_bins* b, const kr_ray_f64* rays, int64_
     if (disc_count) *disc_count = dc;
 }
 
+/* returning-radiation classification: the loop body of src/return_radiation/disc_source_photonfrac_r.cpp:97-126
+ * (stale app: `ray_cosalpha(ray)` / `ray_beta(ray)` / map_results() are read here from rays[].alpha (= cos alpha,
+ * pointsource.cpp:48), rays[].beta and the record itself).  out = {ray_count, return, escape, lost}. */
+void kro_reduce_return_f64(const kr_return_bins* b, const kr_ray_f64* rays, int64_t n, double out[4])
+{
+    double ray_count = 0, return_count = 0, escape_count = 0, lost_count = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const ray_t* ray = &rays[i];
+        if (ray->steps > 0) {
+            const double alpha = acos(ray->alpha);
+            const double beta = ray->beta;
+            double ray_weight = b->plane_iso ? fabs(sin(alpha) * sin(beta)) : 1;
+            if (b->limb) ray_weight *= 1 + 2.06 * (fabs(sin(alpha) * sin(beta)));
+            ray_count += b->weight_norm ? ray_weight : 1;
+            if (ray->theta >= M_PI_2 && ray->r >= b->r_isco && ray->r < b->r_disc) {
+                if (fabs(ray->r - b->source_r) > 0.1 * b->source_r || fabs(ray->phi - b->source_phi) > 0.1) return_count += ray_weight;
+            } else if (ray->r > b->r_esc) {
+                escape_count += ray_weight;
+            } else if (ray->r < b->r_isco) {
+                lost_count += ray_weight;
+            }
+        }
+    }
+    out[0] = ray_count; out[1] = return_count; out[2] = escape_count; out[3] = lost_count;
+}
+
 int kro_max_threads(void)
 {
 #ifdef _OPENMP

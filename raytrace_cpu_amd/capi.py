@@ -63,6 +63,11 @@ class ImageBins(C.Structure):
                [(n, C.c_int32) for n in ("img_nx", "img_ny", "flip_image", "pad")]
 
 
+class ReturnBins(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("r_isco", "r_disc", "r_esc", "source_r", "source_phi")] + \
+               [(n, C.c_int32) for n in ("plane_iso", "limb", "weight_norm", "pad")]
+
+
 def default_params(spin, horizon=None):
     """Raytracer<T> ctor defaults (reference src/raytracer/raytracer.cpp:12-22, raytracer.h:19-44)."""
     p = Params()
@@ -128,6 +133,8 @@ PROTOTYPES = {
     "kr_reduce_emissivity_dev_f64": (_int, [P(EmisBins), _vp, _i64, _vp, _vp]),
     "kr_reduce_image_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
     "kr_reduce_image_dev_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp]),
+    "kr_reduce_return_f64": (_int, [P(ReturnBins), _vp, _i64, P(_dbl * 4)]),
+    "kr_reduce_return_dev_f64": (_int, [P(ReturnBins), _vp, _i64, _vp, _vp]),
     "kr_debug_arith_f64": (_int, [_int, _vp, _vp, _vp, _i64]),
     "kr_malloc": (_int, [P(_vp), _i64]),
     "kr_free": (_int, [_vp]),

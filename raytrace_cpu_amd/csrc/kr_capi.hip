@@ -26,6 +26,7 @@ int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t fi
 int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st);
 int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st);
 int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st);
+int reduce_return_dev(const kr_return_bins* b, const void* d, int64_t n, void* d_out4, hipStream_t st);
 int arith_probe_dev(int op, const double* a, const double* b, double* out, int64_t n);
 
 static thread_local std::string g_error;
@@ -385,6 +386,28 @@ int kr_reduce_image_f64(const kr_image_bins* b, const kr_ray_f64* rays, int64_t 
     std::memcpy(emis, &h[6 * npix], npix * sizeof(double));
     if (disc_count) *disc_count = (int64_t) h[7 * npix];
     return KR_OK;
+}
+
+int kr_reduce_return_dev_f64(const kr_return_bins* b, const void* d, int64_t n, void* d_out4, void* st)
+{
+    if (!b || !d_out4) { set_error("kr_reduce_return: null argument"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : reduce_return_dev(b, d, n, d_out4, (hipStream_t) st);
+}
+
+int kr_reduce_return_f64(const kr_return_bins* b, const kr_ray_f64* rays, int64_t n, double out[4])
+{
+    if (!b || !out) { set_error("kr_reduce_return: null argument"); return KR_EINVAL; }
+    return with_staged_rays((void*) rays, n, sizeof(kr_ray_f64), true, false, nullptr, [&](void* d) {
+        DeviceBuffer acc;
+        int r2 = acc.alloc(4 * sizeof(double));
+        if (r2 != KR_OK) return r2;
+        KR_HIP(hipMemset(acc.p, 0, 4 * sizeof(double)));
+        r2 = reduce_return_dev(b, d, n, acc.p, nullptr);
+        if (r2 != KR_OK) return r2;
+        KR_HIP(hipMemcpy(out, acc.p, 4 * sizeof(double), hipMemcpyDeviceToHost));
+        return (int) KR_OK;
+    });
 }
 
 // ---- diagnostics ---------------------------------------------------------------------------------------------

@@ -375,6 +375,38 @@ reduce_image_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_image_b
 
 }  // namespace
 
+// ---- returning-radiation classification (disc_source_photonfrac_r.cpp:97-126) ------------------------------------
+// out4 = {ray_count, return, escape, lost}; per-wave shuffle reduction, one atomic per wave and word
+__global__ void __launch_bounds__(kBlock)
+reduce_return_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_return_bins b, double* __restrict__ out4)
+{
+    double acc[4] = {0, 0, 0, 0};
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        const kr_ray_f64* ray = &rays[i];
+        if (!(ray->steps > 0)) continue;
+        const double alpha = kr_acos(ray->alpha);          // rays[].alpha holds cos(alpha)
+        const double sasb = kr_abs(kr_sin(alpha) * kr_sin(ray->beta));
+        double w = b.plane_iso ? sasb : 1;
+        if (b.limb) w *= 1 + 2.06 * sasb;
+        acc[0] += b.weight_norm ? w : 1;
+        const double r = ray->r;
+        if (ray->theta >= kPi2 && r >= b.r_isco && r < b.r_disc) {
+            if (kr_abs(r - b.source_r) > 0.1 * b.source_r || kr_abs(ray->phi - b.source_phi) > 0.1) acc[1] += w;
+        } else if (r > b.r_esc) {
+            acc[2] += w;
+        } else if (r < b.r_isco) {
+            acc[3] += w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(&out4[k], v);
+    }
+}
+
 // ---- diagnostics: the device arithmetic primitives the trace kernel is built from, exposed one at a time so that a
 //      test can compare them with the host's IEEE results (tests/test_gpu_primitives.py) ------------------------------
 __global__ void __launch_bounds__(kBlock) arith_probe_kernel(int op, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, long long n)
@@ -484,6 +516,14 @@ int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void*
         hipLaunchKernelGGL(reduce_emissivity_kernel<true>, dim3(grid), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_hist);
     else
         hipLaunchKernelGGL(reduce_emissivity_kernel<false>, dim3(grid), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_hist);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int reduce_return_dev(const kr_return_bins* b, const void* d, int64_t n, void* d_out4, hipStream_t st)
+{
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(reduce_return_kernel, dim3(grid_for(n, 256 * 4)), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_out4);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }

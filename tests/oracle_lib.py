@@ -55,6 +55,7 @@ def oracle():
             "kro_imageplane_init_f64": (_int, [P(capi.ImagePlaneSpec), _vp, _i64]),
             "kro_reduce_emissivity_f64": (None, [P(capi.EmisBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
             "kro_reduce_image_f64": (None, [P(capi.ImageBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
+            "kro_reduce_return_f64": (None, [P(capi.ReturnBins), _vp, _i64, P(_dbl * 4)]),
             "kro_max_threads": (_int, []),
         }
         for name, (res, args) in protos.items():

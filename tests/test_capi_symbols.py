@@ -40,7 +40,7 @@ def test_struct_layouts_match_header(lib):
     assert capi.RAY_F64.fields["steps"][1] == 104 and capi.RAY_F64.fields["alpha"][1] == 128
     assert C.sizeof(capi.Params) == 128 and C.sizeof(capi.Stats) == 72
     assert C.sizeof(capi.PointSourceSpec) == 112 and C.sizeof(capi.ImagePlaneSpec) == 88
-    assert C.sizeof(capi.EmisBins) == 56 and C.sizeof(capi.ImageBins) == 104
+    assert C.sizeof(capi.EmisBins) == 56 and C.sizeof(capi.ImageBins) == 104 and C.sizeof(capi.ReturnBins) == 56
     p = capi.Params()
     lib.kr_params_default(C.byref(p), 0.998)
     q = capi.default_params(0.998)

@@ -334,3 +334,35 @@ def test_degenerate_denominators_match_oracle(krlib):
         # records poisoned by a zero denominator are non-finite on both sides (inf vs NaN may differ) and end at once
         bad = ~np.isfinite(want["r"])
         assert (~np.isfinite(out["r"][bad])).all()
+
+
+def test_return_radiation_vs_oracle(krlib):
+    """BASELINE configs[4] semantics (disc -> disc returning radiation, per-radius relaunch): source on the disc at r_s,
+    Keplerian, beta in [0, pi), Euler to 1.1 r_esc, then the escape / return / lost classification
+    (src/return_radiation/disc_source_photonfrac_r.cpp:74-135).  That app is stale in the reference (does not compile),
+    so the classification itself is pinned only by the oracle's restatement of its loop body; the trace is pinned as usual."""
+    o, lib = ol.oracle(), api.lib()
+    r_isco = o.kro_kerr_isco(gc.SPIN, 1)
+    for r_s in (2.0, 6.0, 30.0):
+        V = o.kro_disc_velocity(r_s, gc.SPIN, 1)
+        spec = ol.pointsource_spec([0.0, r_s, np.pi / 2 - 1e-6, 1.5707], V, gc.SPIN, 0.05, 0.05, cosalpha0=-0.995, cosalphamax=0.995, beta0=0.0, betamax=np.pi)
+        init = ol.oracle_pointsource(spec)
+        o.kro_redshift_start_f64(gc.SPIN, V, 0, 0, ol.ptr(init), len(init))
+        p = capi.default_params(gc.SPIN)
+        p.integrator, p.r_max = capi.EULER, 1100.0
+        want, _ = ol.oracle_trace(p, init)
+        o.kro_range_phi_f64(-np.pi, np.pi, ol.ptr(want), len(want))
+        out, _ = api.trace(p, init)
+        api.range_phi(out)
+        b = capi.ReturnBins()
+        b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = r_isco, 500.0, 1000.0, r_s, 1.5707
+        b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
+        w4, g4 = (C.c_double * 4)(), (C.c_double * 4)()
+        o.kro_reduce_return_f64(C.byref(b), ol.ptr(want), len(want), C.byref(w4))
+        capi.check(lib, lib.kr_reduce_return_f64(C.byref(b), ol.ptr(out), len(out), C.byref(g4)), "reduce_return")
+        w, g = np.array(w4), np.array(g4)
+        assert w[0] > 0 and (w[1:] > 0).any()
+        np.testing.assert_allclose(g, w, rtol=1e-6, atol=1e-9 * w[0])
+        # the GPU reducer on the CPU's rays agrees to summation order
+        capi.check(lib, lib.kr_reduce_return_f64(C.byref(b), ol.ptr(want), len(want), C.byref(g4)), "reduce_return")
+        np.testing.assert_allclose(np.array(g4), w, rtol=1e-12)
