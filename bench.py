@@ -305,7 +305,8 @@ def main():
     lib = api.lib()
     capi.check(lib, lib.kr_set_device(local_rank), "kr_set_device")
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("KR_BENCH_FORCE_DIST"):
+        # under torch.distributed.run the collective path is used even with one rank, so that it is exercised on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -404,7 +405,9 @@ def main():
             out["fast_math_opt_in"] = fast_extra
         if args.integrator == "rk45":
             out["rk45"] = {k: int(stats_last[k]) for k in ("rk45_attempts", "rk45_rejects", "rk45_stationary_steps")}
-        if not args.no_cpu_baseline and args.workload == "emissivity":
+        if world > 1:
+            pass                                    # cpu_baseline is an N = 1 leg only
+        elif not args.no_cpu_baseline and args.workload == "emissivity":
             out["cpu_baseline"] = cpu_baseline(args, capi, api, wl.method, wl.d)
         elif not args.no_cpu_baseline and args.workload == "imageplane":
             out["cpu_baseline"] = cpu_baseline_imageplane(args, capi, api, wl)
