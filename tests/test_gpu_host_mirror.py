@@ -1,0 +1,17 @@
+"""GPU: C++ test program over the host-side mirror of the reference class API (tests/cpp/host_api_test.cpp)."""
+import os
+import subprocess
+
+import pytest
+
+import golden_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_host_api_program():
+    d = os.path.join(gc.ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(gc.ROOT, "raytrace_cpu_amd", "host")])
+    subprocess.check_call(["make", "-s", "-C", d])
+    r = subprocess.run([os.path.join(d, "host_api_test")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout[-3000:] + r.stderr[-1000:]
