@@ -7,8 +7,8 @@
 template <typename T>
 ImagePlane<T>::ImagePlane(T dist, T inc, T x0, T xmax, T dx, T y0, T ymax, T dy, T spin, T phi, T precision)
     : Raytracer<T>((((xmax - x0) / dx) + 1) * (((ymax - y0) / dy) + 1), -1 * spin, precision),
-      D(dist), incl(inc), phi0(phi), m_x0(x0), m_xmax(xmax), m_dx(dx), m_y0(y0), m_ymax(ymax), m_dy(dy),
-      Nx(((xmax - x0) / dx) + 1), Ny(((ymax - y0) / dy) + 1)
+      Nx(((xmax - x0) / dx) + 1), Ny(((ymax - y0) / dy) + 1),
+      m_x0(x0), m_xmax(xmax), m_dx(dx), m_y0(y0), m_ymax(ymax), m_dy(dy), D(dist), incl(inc), phi0(phi)
 {
     init_image_plane(D, incl * M_PI / 180, phi0, x0, xmax, dx, y0, ymax, dy);
 }

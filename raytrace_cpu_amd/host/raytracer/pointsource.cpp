@@ -7,7 +7,7 @@
 
 template <typename T>
 PointSource<T>::PointSource(T* pos, T V, T spin, T tol, T dcosalpha, T dbeta, T cosalpha0, T cosalphamax, T beta0, T betamax, T E)
-    : Raytracer<T>((((cosalphamax - cosalpha0) / dcosalpha) + 1) * (((betamax - beta0) / dbeta) + 1), spin, tol), energy(E), velocity(V)
+    : Raytracer<T>((((cosalphamax - cosalpha0) / dcosalpha) + 1) * (((betamax - beta0) / dbeta) + 1), spin, tol), velocity(V), energy(E)
 {
     n_cosalpha = ((cosalphamax - cosalpha0) / dcosalpha) + 1;
     n_beta = ((betamax - beta0) / dbeta) + 1;
