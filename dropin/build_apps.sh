@@ -49,6 +49,9 @@ if [ -f $CFITS_INC/fitsio.h ]; then
     # link cfitsio by path: -L$CFITS_LIB would also pull conda's (older) libstdc++ ahead of the system one that
     # libamdhip64 needs.  Run the binaries with LD_PRELOAD=<system libstdc++.so.6> LD_LIBRARY_PATH=$CFITS_LIB.
     LINK="$CFITS_LIB/libcfitsio.so" build imageplane_disc_image $REF/src/imageplane/imageplane_disc_image.cpp "-fpermissive -I$CFITS_INC"
+    for app in caustic_discplane caustic_sourceplane caustic_plane; do
+        LINK="$CFITS_LIB/libcfitsio.so" build $app $REF/src/caustic/$app.cpp "-fpermissive -I$CFITS_INC"
+    done
 else
     echo "cfitsio not found: imageplane_disc_image skipped"
 fi

@@ -16,6 +16,11 @@ rm -rf $W
 rm -f $G/imageplane_rk4.fits $G/imageplane_rk45.fits
 $APPS/imageplane_disc_image --parfile=$G/imageplane_rk4.par  --outfile=$G/imageplane_rk4.fits  > /dev/null
 $APPS/imageplane_disc_image --parfile=$G/imageplane_rk45.par --outfile=$G/imageplane_rk45.fits > /dev/null
+for c in caustic_discplane caustic_discplane_rk45 caustic_sourceplane; do
+    rm -f $G/$c.fits
+    app=${c%_rk45}
+    $APPS/$app --parfile=$G/$c.par --outfile=$G/$c.fits > /dev/null
+done
 $APPS/raytrace_rk4_test    | tail -16 > $G/raytrace_rk4_test.txt
 $APPS/emissivity_rk45_test | tail -40 > $G/emissivity_rk45_test.txt
 ls -la $G
