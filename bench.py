@@ -63,7 +63,14 @@ def emis_bins(capi, kerr_isco, n_primary):
     return b
 
 
-def cpu_baseline(args, capi, api, integrator, d_full):
+ARITHMETIC_NOTE = {
+    "strict": "strict: IEEE fp64, reference association, every ray",
+    "hybrid": "hybrid: rays whose theta-dot^2 or h is a cancellation residue -> strict IEEE path (side launch on SIMDs of their own); all others -> shared-reciprocal / Newton rcp,rsq / FMA path",
+    "fast": "fast (opt-in): shared-reciprocal / Newton rcp,rsq / FMA path for every ray; ill-conditioned rays may end differently",
+}
+
+
+def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
     """Times the CPU path on a bounded sample of the same workload (same source, same angular ranges, coarser
     grid), on this box's host cores, and checks the GPU histogram of that same sample against it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -104,6 +111,7 @@ def cpu_baseline(args, capi, api, integrator, d_full):
     o.kro_redshift_f64(SPIN, -1.0, 0, 0, 0, ol.ptr(cpu_rays), len(cpu_rays))
     n_primary = int(((spec.cosalphamax - spec.cosalpha0) / spec.dcosalpha) * ((spec.betamax - spec.beta0) / spec.dbeta))
     bins = emis_bins(capi, api.lib().kr_kerr_isco(SPIN, 1), n_primary)
+    p.flags = flags                                    # the arithmetic mode the headline was measured in
     gpu_rays, _ = api.trace(p, init)
     api.range_phi(gpu_rays)
     api.redshift(SPIN, -1.0, 0, 0, gpu_rays)
@@ -120,6 +128,18 @@ def cpu_baseline(args, capi, api, integrator, d_full):
         ww = w[same & (cnt > 0)]
         if len(ww):
             worst = max(worst, float(np.max(np.abs(g - ww) / np.abs(ww))))
+    # ... and ray by ray: integer outcome fields equal, positions / redshift within 1e-9 relative
+    ints_same = np.ones(len(init), dtype=bool)
+    for k in ("status", "rdot_flips", "equatorial_crossings", "steps"):
+        ints_same &= gpu_rays[k] == cpu_rays[k]
+    close = np.ones(len(init), dtype=bool)
+    with np.errstate(invalid="ignore"):
+        for k in ("r", "theta", "redshift"):
+            close &= ~(np.abs(gpu_rays[k] - cpu_rays[k]) > 1e-9 * np.maximum(np.abs(cpu_rays[k]), 1e-300))
+    on_disc = valid & ((cpu_rays["status"] & 1) != 0)
+    rays_check = {"rays": n_valid, "integer_fields_differ": int((valid & ~ints_same).sum()),
+                  "disc_rays": int(on_disc.sum()), "disc_rays_beyond_1e-9": int((on_disc & ints_same & ~close).sum()),
+                  "bit_identical_r_theta_frac": float(((gpu_rays["r"] == cpu_rays["r"]) & (gpu_rays["theta"] == cpu_rays["theta"]))[valid].mean())}
     unit = "rays/s"
     return {
         "value": n_valid / wall, "unit": unit, "cores": cores, "kind": kind,
@@ -128,6 +148,7 @@ def cpu_baseline(args, capi, api, integrator, d_full):
         "steps_per_sec": steps / wall, "wall_s": wall,
         "bins_check": {"bins": int(nr), "bins_count_mismatch": int((~same).sum()), "max_count_diff": int(np.abs(cnt - got["count"]).max()),
                        "max_rel_diff_on_matching_bins": worst, "tolerance": 1e-6},
+        "rays_check": rays_check,
     }
 
 
@@ -284,7 +305,9 @@ def main():
     ap.add_argument("--radii", type=int, default=100, help="return_radiation: number of source radii")
     ap.add_argument("--rays", type=float, default=0, help="rays per GPU (default: 1e7 emissivity = BASELINE configs[1]; 4097^2 imageplane = configs[3])")
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
-    ap.add_argument("--fast-math", action="store_true", help="KR_FLAG_FAST_MATH (opt-in; see include/kr_trace.h)")
+    ap.add_argument("--arithmetic", default="hybrid", choices=["hybrid", "strict", "fast"],
+                    help="hybrid (KR_FLAG_HYBRID: strict for ill-conditioned rays, fast for the rest), strict (flags = 0), fast (KR_FLAG_FAST_MATH)")
+    ap.add_argument("--fast-math", action="store_true", help="same as --arithmetic fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-math-extra", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=float, default=0)
@@ -315,7 +338,12 @@ def main():
         args.integrator = "euler"         # the reference driver uses the Euler integrator (disc_source_photonfrac_r.cpp:92)
     wl = {"emissivity": EmissivityWorkload, "imageplane": ImagePlaneWorkload, "return_radiation": ReturnRadiationWorkload}[args.workload](args, lib, capi, api, rank, world)
     if args.fast_math:
-        wl.p.flags |= capi.FLAG_FAST_MATH
+        args.arithmetic = "fast"
+    if args.integrator == "euler" and args.arithmetic == "hybrid" and args.workload == "return_radiation":
+        pass                                             # hybrid applies to every integrator
+    mode_flags = {"strict": 0, "hybrid": capi.FLAG_HYBRID, "fast": capi.FLAG_FAST_MATH}
+    mode_mask = capi.FLAG_HYBRID | capi.FLAG_FAST_MATH
+    wl.p.flags = (wl.p.flags & ~mode_mask) | mode_flags[args.arithmetic]
     n = wl.n
     rays = torch.empty(n * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda")
     res = torch.zeros(wl.result_words, dtype=torch.float64, device="cuda")
@@ -356,20 +384,24 @@ def main():
         traced_all, steps_all = traced, steps_total
 
     h = res.cpu().numpy()
-    # the opt-in KR_FLAG_FAST_MATH path on the same workload, reported beside the headline (never AS the headline)
-    fast_extra = None
-    if world == 1 and not args.fast_math and not args.no_fast_math_extra:
-        wl.p.flags |= capi.FLAG_FAST_MATH
-        one_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        fst = [one_step() for _ in range(2)]
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t1) / 2
-        wl.p.flags &= ~capi.FLAG_FAST_MATH
-        fast_extra = {"value": fst[-1]["rays_traced"] / dt, "unit": "rays/s", "rk_steps_per_sec": fst[-1]["steps_total"] / dt,
-                      "avg_kernel_ms": float(np.mean([x["kernel_ms"] for x in fst])), "ms_per_step": 1e3 * dt,
-                      "note": "kr_params.flags |= KR_FLAG_FAST_MATH: shared reciprocals, Newton rcp/rsq, FMA; same tolerances except knife-edge rays (DESIGN.md)"}
+    # the other two arithmetic modes on the same workload, reported beside the headline
+    others = None
+    if world == 1 and not args.no_fast_math_extra:
+        others = {}
+        for mode in ("strict", "hybrid", "fast"):
+            if mode == args.arithmetic:
+                continue
+            keep = wl.p.flags
+            wl.p.flags = (wl.p.flags & ~mode_mask) | mode_flags[mode]
+            one_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fst = [one_step() for _ in range(2)]
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 2
+            wl.p.flags = keep
+            others[mode] = {"value": fst[-1]["rays_traced"] / dt, "unit": "rays/s", "rk_steps_per_sec": fst[-1]["steps_total"] / dt,
+                            "avg_kernel_ms": float(np.mean([x["kernel_ms"] for x in fst])), "ms_per_step": 1e3 * dt}
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
@@ -388,7 +420,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.describe, "rays_per_gpu": int(traced), "allocated_rays_per_gpu": int(n), "rays_total": int(traced_all),
-                       "integrator": args.integrator, "arithmetic": "fast_math (opt-in)" if args.fast_math else "strict IEEE, reference association", "pipeline": wl.pipeline + ("+rccl_allreduce" if world > 1 else ""), "sharding": wl.sharding},
+                       "integrator": args.integrator, "arithmetic": ARITHMETIC_NOTE[args.arithmetic], "rays_on_strict_side_launch": int(stats_last.get("rays_strict_side", 0)), "pipeline": wl.pipeline + ("+rccl_allreduce" if world > 1 else ""), "sharding": wl.sharding},
             "rk_steps_per_sec": steps_all * args.steps / elapsed,
             "rk_steps_per_launch": int(steps_total), "mean_steps_per_ray": steps_total / max(traced, 1),
             "roofline": {"bound": "valu_fp64", "kernel": "kr::trace_kernel<double>", "achieved": achieved_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
@@ -401,14 +433,14 @@ def main():
                          "note": "latency-bound scalar fp64 ODE: neither HBM nor MFMA bounds it (SURVEY.md 8d); priced against vector fp64 peak"},
         }
         out.update(wl.summary(h))
-        if fast_extra is not None:
-            out["fast_math_opt_in"] = fast_extra
+        if others:
+            out["other_arithmetic_modes"] = others
         if args.integrator == "rk45":
             out["rk45"] = {k: int(stats_last[k]) for k in ("rk45_attempts", "rk45_rejects", "rk45_stationary_steps")}
         if world > 1:
             pass                                    # cpu_baseline is an N = 1 leg only
         elif not args.no_cpu_baseline and args.workload == "emissivity":
-            out["cpu_baseline"] = cpu_baseline(args, capi, api, wl.method, wl.d)
+            out["cpu_baseline"] = cpu_baseline(args, capi, api, wl.method, wl.d, mode_flags[args.arithmetic])
         elif not args.no_cpu_baseline and args.workload == "imageplane":
             out["cpu_baseline"] = cpu_baseline_imageplane(args, capi, api, wl)
         print(json.dumps(out), flush=True)

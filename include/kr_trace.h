@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 2
+#define KR_ABI_VERSION 3
 
 /* error codes */
 #define KR_OK          0
@@ -66,6 +66,10 @@ extern "C" {
                                            contraction instead of IEEE division/sqrt (a few ulp per operation; ~1.4x faster).
                                            0 = strict: the reference's association with IEEE + - * / sqrt, no contraction. */
 
+#define KR_FLAG_HYBRID        (1 << 1)  /* f64 trace only: rays whose polar motion / axial angular momentum is a cancellation residue
+                                           (their outcome in the reference is decided by rounding) and NaN rays are integrated on
+                                           the strict path, in a side launch whose waves own their SIMDs; all other rays take the
+                                           fast-math path.  Reproduces the reference on every ray class at ~1.5x the strict speed. */
 #define KR_FLAG_BLOCKS_PER_CU(n)      (((n) & 0xF) << 8)   /* resident 256-thread workgroups per CU for the trace kernel, 0 = default (2) */
 #define KR_FLAG_GET_BLOCKS_PER_CU(f)  (((f) >> 8) & 0xF)
 
@@ -126,6 +130,7 @@ typedef struct kr_stats {
     int64_t rk45_rejects;    /* RK45: trial steps rejected */
     double  kernel_ms;       /* trace kernel duration, HIP events on the launch stream */
     double  h2d_ms, d2h_ms;  /* host-buffer entry points only */
+    int64_t rays_strict_side;       /* KR_FLAG_HYBRID: rays classified ill-conditioned and traced by the strict side launch */
     int64_t rk45_stationary_steps;  /* RK45: steps (included in steps_total and rk45_attempts) that were replayed as bare t/phi
                                        additions after a captured ray reached an exact fp64 fixed point in (r, theta, step);
                                        bit-identical to iterating them (kr_device.hpp::step_rk45) */

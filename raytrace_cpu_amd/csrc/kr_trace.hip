@@ -107,10 +107,17 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 // ---- the persistent kernel ------------------------------------------------------------------------
 // METHOD: KR_EULER / KR_RK4 / KR_RK45.  REFILL_MIN: a wave goes back to the queue when at least this many of its
 // lanes are free (or when none holds a ray).
-template <typename T, int METHOD, bool USE_DEST, bool FAST, int REFILL_MIN>
+// `list` (optional): the launch works on rays list[0 .. n) instead of rays 0 .. n); `n_ptr` (optional): n is read from
+// device memory (the classification kernel of the hybrid path produced it).  HOG: the kernel claims the whole register
+// file (512 VGPR+AGPR per lane), so each of its waves owns its SIMD and no other kernel's wave can be co-resident on
+// the CUs it occupies -- used for the few ill-conditioned / long rays that define the critical path.
+template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
 __global__ void __launch_bounds__(kBlock, KR_MIN_WAVES)
-trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters)
+trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
+             const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr)
 {
+    if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
+    if (n_ptr) n = (long long) *n_ptr;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_bit = 1ull << lane;
 
@@ -137,8 +144,9 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
             base = __shfl(base, leader, 64);
             if (base + (unsigned long long) n_need >= (unsigned long long) n) exhausted = true;
             if (!have) {
-                const long long mine = (long long) base + __popcll(need & (lane_bit - 1));
-                if (mine < n) {
+                const long long slot = (long long) base + __popcll(need & (lane_bit - 1));
+                if (slot < n) {
+                    const long long mine = list ? (long long) list[slot] : slot;
                     load_ray(&rays[mine], s);
                     // skip rule of run_raytrace (raytracer.cpp:116-117)
                     if (s.steps0 >= 0 && s.steps0 < c.steplim) {
@@ -219,10 +227,55 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     }
 }
 
+// ---- hybrid path: which rays must be integrated with the reference's exact arithmetic? ----------------------------
+// A ray is ILL-CONDITIONED when its polar motion or its axial angular momentum is a cancellation residue:
+//   thetadot^2 rho^4 = Q + (k a cos + h cos/sin)(k a cos - h cos/sin)  with |sum| <= 1e-9 (|Q| + |product|), or |h| < 1e-13
+// (PointSource rays emitted at beta = -pi: sin(beta) = -1.2e-16; ImagePlane rays on x = 0 / y = 0; NaN rays).  The
+// reference's outcome for such a ray is decided by the rounding of exactly its own operation sequence, so only the
+// strict path reproduces it; every other ray is insensitive to a few ulp per operation (tests/parity.py) and may
+// take the fast path.  In the lamp-post workloads the ill-conditioned rays are also the longest ones (they ride the
+// polar axis in MIN_STEP steps), which is why they get SIMDs of their own (HOG launch).
+__global__ void __launch_bounds__(kBlock)
+classify_kernel(const kr_ray_f64* __restrict__ rays, long long n, double a, int* __restrict__ list_fast, int* __restrict__ list_strict,
+                unsigned long long* __restrict__ counts)
+{
+    {   // one ray per work-item: the pass is a 4-field gather over 144-byte records, so it wants every load in flight at once
+        const long long i = blockIdx.x * (long long) kBlock + threadIdx.x;
+        bool strict = false, valid = i < n;
+        if (valid) {
+            const kr_ray_f64* ray = &rays[i];
+            const double k = ray->k, h = ray->h, Q = ray->Q, theta = ray->theta;
+            double sn, cs;
+            kr_sincos_f64(theta, sn, cs);
+            const double kac = k * a * cs;
+            const double hcs = h * cs / sn;
+            const double prod = (kac + hcs) * (kac - hcs);
+            const double sum = Q + prod;
+            strict = !(__builtin_fabs(sum) > 1e-9 * (__builtin_fabs(Q) + __builtin_fabs(prod))) || !(__builtin_fabs(h) >= 1e-13);
+        }
+        // wave-aggregated append to one of the two lists
+        const unsigned long long m_strict = __ballot(valid && strict), m_fast = __ballot(valid && !strict);
+        const int lane = threadIdx.x & 63;
+        const unsigned long long below = (1ull << lane) - 1;
+        unsigned long long base_s = 0, base_f = 0;
+        if (lane == 0) {
+            if (m_strict) base_s = atomicAdd(&counts[1], (unsigned long long) __popcll(m_strict));
+            if (m_fast) base_f = atomicAdd(&counts[0], (unsigned long long) __popcll(m_fast));
+        }
+        base_s = __shfl(base_s, 0, 64);
+        base_f = __shfl(base_f, 0, 64);
+        if (valid && strict) list_strict[base_s + __popcll(m_strict & below)] = (int) i;
+        if (valid && !strict) list_fast[base_f + __popcll(m_fast & below)] = (int) i;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 struct DeviceScratch {
-    unsigned long long* counters = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long* counters = nullptr;      // 3 blocks of kCounters: main launch, side launch, {n_fast, n_strict}
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_classified = nullptr, ev_side_done = nullptr;
+    hipStream_t side_stream = nullptr;
+    int* lists = nullptr;                        // 2 x capacity ray indices (hybrid path)
+    int64_t list_capacity = 0;
     int cus = 0;
 };
 std::mutex g_mu;
@@ -236,9 +289,12 @@ int scratch_for_current(DeviceScratch** out)
     std::lock_guard<std::mutex> lk(g_mu);
     DeviceScratch& sc = g_scratch[dev];
     if (!sc.counters) {
-        KR_HIP(hipMalloc((void**) &sc.counters, kCounters * sizeof(unsigned long long)));
+        KR_HIP(hipMalloc((void**) &sc.counters, 3 * kCounters * sizeof(unsigned long long)));
         KR_HIP(hipEventCreate(&sc.ev0));
         KR_HIP(hipEventCreate(&sc.ev1));
+        KR_HIP(hipEventCreateWithFlags(&sc.ev_classified, hipEventDisableTiming));
+        KR_HIP(hipEventCreateWithFlags(&sc.ev_side_done, hipEventDisableTiming));
+        KR_HIP(hipStreamCreateWithFlags(&sc.side_stream, hipStreamNonBlocking));
         hipDeviceProp_t prop;
         KR_HIP(hipGetDeviceProperties(&prop, dev));
         sc.cus = prop.multiProcessorCount;
@@ -263,12 +319,18 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
     return c;
 }
 
-template <typename T, int METHOD, bool USE_DEST, bool FAST>
+struct ListArgs {
+    const int* list = nullptr;                    // ray indices, or null for 0 .. n
+    const unsigned long long* n_ptr = nullptr;    // item count in device memory, or null (use n)
+    int fixed_grid = 0;                           // > 0: launch exactly this many workgroups
+};
+
+template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG = false>
 int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, unsigned long long* counters, int cus,
-           hipStream_t stream, int max_blocks_per_cu)
+           hipStream_t stream, int max_blocks_per_cu, ListArgs la = ListArgs())
 {
     constexpr int kRefill = KR_REFILL_MIN;
-    auto kern = trace_kernel<T, METHOD, USE_DEST, FAST, kRefill>;
+    auto kern = trace_kernel<T, METHOD, USE_DEST, FAST, HOG, kRefill>;
     int blocks_per_cu = 0;
     KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, kBlock, 0));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
@@ -287,9 +349,67 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     if (want < blocks_per_cu) blocks_per_cu = want;
     const int64_t resident = (int64_t) cus * blocks_per_cu;
     const int64_t wanted = (n + kBlock - 1) / kBlock;
-    const int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, rays, (long long) n, c, counters);
+    int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
+    if (la.fixed_grid > 0) grid = la.fixed_grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr);
     KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
+// one trace launch of the requested flavour (double only): FAST over `la` on `stream`, or strict HOG over `la`
+template <bool FAST, bool HOG>
+int launch_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, const TraceConsts<double>& c, unsigned long long* counters, int cus,
+               hipStream_t stream, int mb, const ListArgs& la)
+{
+    const bool dest = (p->stop_kind != KR_STOP_THETA);
+    switch (p->integrator) {
+        case KR_EULER: return launch<double, KR_EULER, false, FAST, HOG>(rays, n, c, counters, cus, stream, mb, la);
+        case KR_RK4:
+            return dest ? launch<double, KR_RK4, true, FAST, HOG>(rays, n, c, counters, cus, stream, mb, la)
+                        : launch<double, KR_RK4, false, FAST, HOG>(rays, n, c, counters, cus, stream, mb, la);
+        default:
+            return dest ? launch<double, KR_RK45, true, FAST, HOG>(rays, n, c, counters, cus, stream, mb, la)
+                        : launch<double, KR_RK45, false, FAST, HOG>(rays, n, c, counters, cus, stream, mb, la);
+    }
+}
+
+// KR_FLAG_HYBRID: classify -> [side stream] strict HOG launch over the ill-conditioned rays  ||  [stream] fast launch over the rest
+int dispatch_hybrid(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, DeviceScratch* sc, hipStream_t stream)
+{
+    if (n > 0x7fffffff) { set_error("kr_trace: hybrid path indexes rays with 32 bits"); return KR_EINVAL; }
+    if (sc->list_capacity < n) {
+        if (sc->lists) KR_HIP(hipFree(sc->lists));
+        sc->lists = nullptr;
+        sc->list_capacity = 0;
+        KR_HIP(hipMalloc((void**) &sc->lists, (size_t) 2 * (size_t) n * sizeof(int)));
+        sc->list_capacity = n;
+    }
+    int* list_fast = sc->lists;
+    int* list_strict = sc->lists + n;
+    unsigned long long* counts = sc->counters + 2 * kCounters;     // [0] n_fast, [1] n_strict (zeroed by the caller's memset)
+    const TraceConsts<double> c = make_consts<double>(p, steplim);
+    const int mb = KR_FLAG_GET_BLOCKS_PER_CU(p->flags);
+    const int cgrid = (int) ((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, list_fast, list_strict, counts);
+    KR_HIP(hipGetLastError());
+    KR_HIP(hipEventRecord(sc->ev_classified, stream));
+    // The strict launch goes FIRST and on the caller's stream (right behind the classification, no cross-queue latency), so its
+    // workgroups are placed while the chip is still empty; the fast launch arrives through the event on the side stream and
+    // fills what is left.  (The other way round the fast launch takes every SIMD's registers and the strict one waits for it.)
+    ListArgs strict_la;
+    strict_la.list = list_strict;
+    strict_la.n_ptr = counts + 1;
+    strict_la.fixed_grid = std::max(1, std::min(sc->cus / 8, 32));
+    int rc = launch_f64<false, true>(p, rays, n, c, sc->counters + kCounters, sc->cus, stream, 1, strict_la);
+    if (rc != KR_OK) return rc;
+    KR_HIP(hipStreamWaitEvent(sc->side_stream, sc->ev_classified, 0));
+    ListArgs fast_la;
+    fast_la.list = list_fast;
+    fast_la.n_ptr = counts;
+    rc = launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, sc->side_stream, mb ? mb : 3, fast_la);
+    if (rc != KR_OK) return rc;
+    KR_HIP(hipEventRecord(sc->ev_side_done, sc->side_stream));
+    KR_HIP(hipStreamWaitEvent(stream, sc->ev_side_done, 0));
     return KR_OK;
 }
 
@@ -349,16 +469,21 @@ int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, k
     rc = scratch_for_current(&sc);
     if (rc != KR_OK) return rc;
 
-    KR_HIP(hipMemsetAsync(sc->counters, 0, kCounters * sizeof(unsigned long long), stream));
+    KR_HIP(hipMemsetAsync(sc->counters, 0, 3 * kCounters * sizeof(unsigned long long), stream));
     if (stats) KR_HIP(hipEventRecord(sc->ev0, stream));
+    const bool hybrid = !f32 && (p->flags & KR_FLAG_HYBRID) && !(p->flags & KR_FLAG_FAST_MATH);
     rc = f32 ? dispatch<float>(p, d_rays, n, steplim, sc->counters, sc->cus, stream)
-             : dispatch<double>(p, d_rays, n, steplim, sc->counters, sc->cus, stream);
+             : hybrid ? dispatch_hybrid(p, (kr_ray_f64*) d_rays, n, steplim, sc, stream)
+                      : dispatch<double>(p, d_rays, n, steplim, sc->counters, sc->cus, stream);
     if (rc != KR_OK) return rc;
     if (stats) {
         KR_HIP(hipEventRecord(sc->ev1, stream));
-        unsigned long long h[kCounters];
-        KR_HIP(hipMemcpyAsync(h, sc->counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+        unsigned long long h2[3 * kCounters];
+        KR_HIP(hipMemcpyAsync(h2, sc->counters, sizeof(h2), hipMemcpyDeviceToHost, stream));
         KR_HIP(hipStreamSynchronize(stream));
+        unsigned long long h[kCounters];
+        for (int i = 0; i < kCounters; i++) h[i] = h2[i] + h2[kCounters + i];
+        stats->rays_strict_side = (int64_t) h2[2 * kCounters + 1];
         float ms = 0;
         KR_HIP(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
         stats->rays_traced = (int64_t) h[1];

@@ -79,6 +79,17 @@ Raytracer<T>::~Raytracer()
     delete[] rays;
 }
 
+// Arithmetic of the double-precision trace (include/kr_trace.h), chosen by the environment so that
+// the reference's applications need no new option: KRTRACE_ARITHMETIC = hybrid (default) | strict | fast.
+static int arithmetic_flags()
+{
+    const char* e = std::getenv("KRTRACE_ARITHMETIC");
+    if (!e || !*e || !std::strcmp(e, "hybrid")) return KR_FLAG_HYBRID;
+    if (!std::strcmp(e, "strict")) return 0;
+    if (!std::strcmp(e, "fast")) return KR_FLAG_FAST_MATH;
+    throw std::invalid_argument(std::string("KRTRACE_ARITHMETIC: expected hybrid, strict or fast, got '") + e + "'");
+}
+
 template <typename T>
 void Raytracer<T>::fill_params(void* out, Integrator method, T r_max, int steplim) const
 {
@@ -97,6 +108,7 @@ void Raytracer<T>::fill_params(void* out, Integrator method, T r_max, int stepli
     p->integrator = static_cast<int>(method);   // Euler, RK4, RK45 == KR_EULER, KR_RK4, KR_RK45
     p->stop_kind = KR_STOP_THETA;
     p->steplim = steplim;                        // <= 0 selects STEPLIM / RK45_STEPLIM inside the library
+    p->flags = arithmetic_flags();
 }
 
 template <typename T>

@@ -19,18 +19,21 @@ a = ap.parse_args()
 from raytrace_cpu_amd import _build, capi
 specs = []
 for v in a.variants:
-    tag, _, fl = v.partition(":")
+    tag, _, fl = v.partition(":")          # tag[@kr_flags][:compile,flags]
     specs.append((tag, [f for f in fl.split(",") if f]))
 if a.build:
     for tag, fl in specs:
-        print(_build.build(extra_flags=fl, tag=("" if tag == "base" else tag)))
+        print(_build.build(extra_flags=fl, tag=("" if tag.partition("@")[0] == "base" else tag.partition("@")[0])))
     sys.exit(0)
 
 import bench
 libs = {}
+kr_flags = {}
 for tag, _ in specs:
-    path = capi.LIB_PATH if tag == "base" else capi.LIB_PATH.replace(".so", f"_{tag}.so")
+    name, _, fl = tag.partition("@")
+    path = capi.LIB_PATH if name == "base" else capi.LIB_PATH.replace(".so", f"_{name}.so")
     libs[tag] = capi.load(path)
+    kr_flags[tag] = int(fl or os.environ.get("KR_FLAGS", "0"))
 method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[a.integrator]
 spec = bench.make_spec(capi, bench.grid_spacing_for(a.rays))
 first = libs[specs[0][0]]
@@ -38,7 +41,6 @@ n = first.kr_pointsource_count(C.byref(spec), None, None)
 d_rays = C.c_void_p()
 capi.check(first, first.kr_malloc(C.byref(d_rays), n * 144), "malloc")
 p = capi.default_params(bench.SPIN); p.integrator, p.r_max = method, bench.R_MAX
-p.flags = int(os.environ.get("KR_FLAGS", "0"))
 times = {t: [] for t, _ in specs}; steps = {}
 for rnd in range(a.rounds + 1):
     for tag, _ in specs:
@@ -46,6 +48,7 @@ for rnd in range(a.rounds + 1):
         capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(spec), d_rays, n, None), "init")
         capi.check(lib, lib.kr_redshift_start_dev_f64(bench.SPIN, 0.0, 0, 0, d_rays, n, None), "rs")
         st = capi.Stats()
+        p.flags = kr_flags[tag]
         capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, C.byref(st)), "trace")
         if rnd > 0:
             times[tag].append(st.kernel_ms)
@@ -53,5 +56,5 @@ for rnd in range(a.rounds + 1):
 base = np.median(times[specs[0][0]])
 for tag, fl in specs:
     t = np.array(times[tag])
-    print(json.dumps({"variant": tag, "flags": fl, "rays": int(n), "steps": int(steps[tag]), "kernel_ms_median": float(np.median(t)), "kernel_ms_min": float(t.min()),
+    print(json.dumps({"variant": tag, "flags": fl, "rays": int(n), "steps": int(steps[tag]), "kr_flags": kr_flags[tag], "kernel_ms_median": float(np.median(t)), "kernel_ms_min": float(t.min()),
                       "steps_per_sec": steps[tag] / (np.median(t) * 1e-3), "speedup_vs_first": float(base / np.median(t))}))

@@ -27,21 +27,23 @@ def need(app):
     return path
 
 
-def run_emissivity_app(app):
+def run_emissivity_app(app, arithmetic=None):
     exe = need(app)
+    env = dict(ENV, KRTRACE_ARITHMETIC=arithmetic) if arithmetic else ENV
     with tempfile.TemporaryDirectory() as w:
         os.makedirs(os.path.join(w, "par"))
         os.makedirs(os.path.join(w, "run"))
         shutil.copy(os.path.join(APPS, f"{app}.par"), os.path.join(w, "par", f"{app}.par"))   # the app's built-in default path
         out = os.path.join(w, "out.dat")
-        subprocess.run([exe, f"--outfile={out}"], cwd=os.path.join(w, "run"), check=True, stdout=subprocess.DEVNULL, env=ENV, timeout=300)
+        subprocess.run([exe, f"--outfile={out}"], cwd=os.path.join(w, "run"), check=True, stdout=subprocess.DEVNULL, env=env, timeout=300)
         rows = [l.split() for l in open(out) if l.strip()]
     return np.array([[float(x) for x in r] for r in rows])
 
 
+@pytest.mark.parametrize("arithmetic", [None, "strict"])          # None: the host mirror's default (hybrid)
 @pytest.mark.parametrize("app", ["emissivity", "emissivity_rd"])
-def test_emissivity_apps_match_cpu_output(app):
-    got, want = run_emissivity_app(app), load_dat(f"{app}.dat")
+def test_emissivity_apps_match_cpu_output(app, arithmetic):
+    got, want = run_emissivity_app(app, arithmetic), load_dat(f"{app}.dat")
     assert got.shape == want.shape
     assert (got[:, :2] == want[:, :2]).all()                       # bin radii and areas: host-only code, identical
     dcount = np.abs(got[:, 2] - want[:, 2])

@@ -16,7 +16,8 @@ CASES = gc.cases()
 RUNS = [(c, r) for c in CASES for r in CASES[c]["runs"]]
 
 
-MODES = [pytest.param(0, id="strict"), pytest.param(capi.FLAG_FAST_MATH, id="fastmath")]
+# hybrid = fast arithmetic for well-conditioned rays + strict for the rest: held to the STRICT bar (no ray excluded)
+MODES = [pytest.param(0, id="strict"), pytest.param(capi.FLAG_FAST_MATH, id="fastmath"), pytest.param(capi.FLAG_HYBRID, id="hybrid")]
 
 
 def hip_pipeline(case, params, init, flags=0):
@@ -274,7 +275,7 @@ def test_perf_test_grid_vs_oracle(krlib, method, flags):
     assert res["frac_bad"] <= parity.CHAOTIC_FRAC, res
     bins = gc.emis_bins(spec, nr=30)
     assert parity.compare_bins(api.reduce_emissivity(bins, out), oracle_reduce_emissivity(bins, want)) == []
-    if not flags:
+    if not flags & capi.FLAG_FAST_MATH:
         assert abs(st["steps_total"] - wst["steps_total"]) <= 0.01 * wst["steps_total"]
 
 
