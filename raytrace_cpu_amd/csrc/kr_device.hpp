@@ -255,16 +255,14 @@ KR_DEV double fast_sqrt(double x)      // x >= 0 (callers pass |.|)
     return (x == 0.0 || x == __builtin_inf()) ? x : g;
 }
 
-struct FastAux { double rhosq, sin2theta, inv_rhosq; };
+struct FastAux { double rhosq, sin2theta, inv_rhosq, sn, cs; };
 
 // momentum_from_consts (kerr.h:300-335) with a single reciprocal
-KR_DEV void momentum_fast(double& pt, double& pr, double& ptheta, double& pphi, double k, double h, double Q, int rdot_sign,
-                          int thetadot_sign, double r, double theta, double a, FastAux* aux = nullptr, double* thetadotsq_o = nullptr,
-                          double* rdotsq_o = nullptr)
+KR_DEV void momentum_fast_sc(double& pt, double& pr, double& ptheta, double& pphi, double k, double h, double Q, int rdot_sign,
+                             int thetadot_sign, double r, double s, double c, double a, FastAux* aux = nullptr,
+                             double* thetadotsq_o = nullptr, double* rdotsq_o = nullptr)
 {
 #pragma clang fp contract(fast)
-    double s, c;
-    kr_sincos_f64(theta, s, c);
     const double s2 = s * s;
     const double ac = a * c;
     const double r2 = r * r;
@@ -290,6 +288,48 @@ KR_DEV void momentum_fast(double& pt, double& pr, double& ptheta, double& pphi, 
     if (aux) { aux->rhosq = rhosq; aux->sin2theta = s2; aux->inv_rhosq = inv_rho; }
     if (thetadotsq_o) *thetadotsq_o = thsq;
     if (rdotsq_o) *rdotsq_o = rsq;
+}
+
+KR_DEV void momentum_fast(double& pt, double& pr, double& ptheta, double& pphi, double k, double h, double Q, int rdot_sign,
+                          int thetadot_sign, double r, double theta, double a, FastAux* aux = nullptr, double* thetadotsq_o = nullptr,
+                          double* rdotsq_o = nullptr)
+{
+    double s, c;
+    kr_sincos_f64(theta, s, c);
+    momentum_fast_sc(pt, pr, ptheta, pphi, k, h, Q, rdot_sign, thetadot_sign, r, s, c, a, aux, thetadotsq_o, rdotsq_o);
+}
+
+// sin/cos of theta0 + d from those of theta0 (the stages of one Runge-Kutta step sit within a few per cent of a radian of its
+// base point: |d| <= theta0/50 by the step heuristic unless the MIN_STEP floor is active).  Angle addition with 11th / 10th
+// order Taylor kernels: truncation < 3e-20 for |d| <= 1/8; the sums s0 + (...) keep the rounding at ~1 ulp of the larger
+// operand.  Outside that range, or when the stage lies across the pole (|d| > theta0 / 2: the sine is a cancellation), the
+// full routine is used.
+#ifndef KR_STAGE_SINCOS_NEAR
+#define KR_STAGE_SINCOS_NEAR 1
+#endif
+KR_DEV void sincos_near(double theta0, double s0, double c0, double d, double& s, double& c)
+{
+#pragma clang fp contract(fast)
+    const double ad = __builtin_fabs(d);
+    if (!KR_STAGE_SINCOS_NEAR || !(ad <= 0.125 && ad <= 0.5 * __builtin_fabs(theta0) && ad <= 0.5 * __builtin_fabs(kPi - theta0))) {
+        kr_sincos_f64(theta0 + d, s, c);
+        return;
+    }
+    const double d2 = d * d;
+    double ps = -1.0 / 39916800.0;
+    ps = __builtin_fma(ps, d2, 1.0 / 362880.0);
+    ps = __builtin_fma(ps, d2, -1.0 / 5040.0);
+    ps = __builtin_fma(ps, d2, 1.0 / 120.0);
+    ps = __builtin_fma(ps, d2, -1.0 / 6.0);
+    const double sd = __builtin_fma(d * d2, ps, d);                 // sin d
+    double pc = -1.0 / 3628800.0;
+    pc = __builtin_fma(pc, d2, 1.0 / 40320.0);
+    pc = __builtin_fma(pc, d2, -1.0 / 720.0);
+    pc = __builtin_fma(pc, d2, 1.0 / 24.0);
+    pc = __builtin_fma(pc, d2, -0.5);
+    const double cm = d2 * pc;                                       // cos d - 1
+    s = s0 + __builtin_fma(c0, sd, s0 * cm);
+    c = c0 + __builtin_fma(-s0, sd, c0 * cm);
 }
 
 // k1 with the turning-point logic (see k1_with_flips) on the fast path
@@ -334,7 +374,7 @@ KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
         s.r_was_positive = true;
     }
     s.pr = fast_sqrt(__builtin_fabs(rdotsq)) * s.rdot_sign;
-    aux.rhosq = rhosq; aux.sin2theta = s2; aux.inv_rhosq = inv_rho;
+    aux.rhosq = rhosq; aux.sin2theta = s2; aux.inv_rhosq = inv_rho; aux.sn = sn; aux.cs = c;
     return false;
 }
 
@@ -430,8 +470,8 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
 
     T step;
     T pt1, pr1, ptheta1, pphi1;
+    FastAux aux;
     if constexpr (FAST) {
-        FastAux aux;
         if (k1_with_flips_fast(s, a, aux)) return !(s.steps < c.steplim);
         pt1 = s.pt; pr1 = s.pr; ptheta1 = s.ptheta; pphi1 = s.pphi;
         // same heuristic, quotients as products with Newton-refined reciprocals
@@ -493,16 +533,26 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         s.phi += pphi1 * step;
     } else {
         // k2..k4 use k1's signs and move only (r, theta)  (:889-905)
+        // stage evaluation; the fast path gets sin/cos of the stage angle from those of the base point
+        auto stage = [&](T& pt, T& pr, T& ptheta, T& pphi, T r_stage, T dtheta) {
+            if constexpr (FAST) {
+                double sn, cs;
+                sincos_near(s.theta, aux.sn, aux.cs, dtheta, sn, cs);
+                momentum_fast_sc(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, sn, cs, a);
+            } else {
+                eval<T, false>(pt, pr, ptheta, pphi, s, r_stage, s.theta + dtheta, a);
+            }
+        };
         T pt2, pr2, ptheta2, pphi2;
-        eval<T, FAST>(pt2, pr2, ptheta2, pphi2, s, s.r + (step / 2) * pr1, s.theta + (step / 2) * ptheta1, a);
+        stage(pt2, pr2, ptheta2, pphi2, s.r + (step / 2) * pr1, (step / 2) * ptheta1);
         T acc_t = pt1 + 2 * pt2, acc_phi = pphi1 + 2 * pphi2;
         T pt3, pr3, ptheta3, pphi3;
-        eval<T, FAST>(pt3, pr3, ptheta3, pphi3, s, s.r + (step / 2) * pr2, s.theta + (step / 2) * ptheta2, a);
+        stage(pt3, pr3, ptheta3, pphi3, s.r + (step / 2) * pr2, (step / 2) * ptheta2);
         acc_t = acc_t + 2 * pt3;
         acc_phi = acc_phi + 2 * pphi3;
         T acc_r = pr1 + 2 * pr2 + 2 * pr3, acc_theta = ptheta1 + 2 * ptheta2 + 2 * ptheta3;
         T pt4, pr4, ptheta4, pphi4;
-        eval<T, FAST>(pt4, pr4, ptheta4, pphi4, s, s.r + step * pr3, s.theta + step * ptheta3, a);
+        stage(pt4, pr4, ptheta4, pphi4, s.r + step * pr3, step * ptheta3);
         // x += (step/6)(k1 + 2k2 + 2k3 + k4), summed left to right as in :908-912
         const T w = FAST ? step * T(1.0 / 6.0) : dv<LeanDefault<T>::value>(step, T(6));
         s.t += w * (acc_t + pt4);

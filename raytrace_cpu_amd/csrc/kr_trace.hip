@@ -108,13 +108,14 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 // METHOD: KR_EULER / KR_RK4 / KR_RK45.  REFILL_MIN: a wave goes back to the queue when at least this many of its
 // lanes are free (or when none holds a ray).
 // `list` (optional): the launch works on rays list[0 .. n) instead of rays 0 .. n); `n_ptr` (optional): n is read from
-// device memory (the classification kernel of the hybrid path produced it).  HOG: the kernel claims the whole register
+// device memory (the classification kernel of the hybrid path produced it); `skip` (optional): rays with skip[i] != 0
+// are left alone (they belong to the other launch of the hybrid path).  HOG: the kernel claims the whole register
 // file (512 VGPR+AGPR per lane), so each of its waves owns its SIMD and no other kernel's wave can be co-resident on
 // the CUs it occupies -- used for the few ill-conditioned / long rays that define the critical path.
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
 __global__ void __launch_bounds__(kBlock, KR_MIN_WAVES)
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
-             const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr)
+             const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, const unsigned char* __restrict__ skip)
 {
     if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
     if (n_ptr) n = (long long) *n_ptr;
@@ -145,7 +146,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
             if (base + (unsigned long long) n_need >= (unsigned long long) n) exhausted = true;
             if (!have) {
                 const long long slot = (long long) base + __popcll(need & (lane_bit - 1));
-                if (slot < n) {
+                if (slot < n && !(skip && skip[slot])) {
                     const long long mine = list ? (long long) list[slot] : slot;
                     load_ray(&rays[mine], s);
                     // skip rule of run_raytrace (raytracer.cpp:116-117)
@@ -236,37 +237,34 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
 // take the fast path.  In the lamp-post workloads the ill-conditioned rays are also the longest ones (they ride the
 // polar axis in MIN_STEP steps), which is why they get SIMDs of their own (HOG launch).
 __global__ void __launch_bounds__(kBlock)
-classify_kernel(const kr_ray_f64* __restrict__ rays, long long n, double a, int* __restrict__ list_fast, int* __restrict__ list_strict,
-                unsigned long long* __restrict__ counts)
+classify_kernel(const kr_ray_f64* __restrict__ rays, long long n, double a, unsigned char* __restrict__ strict_mask, int* __restrict__ list_strict,
+                unsigned long long* __restrict__ n_strict)
 {
-    {   // one ray per work-item: the pass is a 4-field gather over 144-byte records, so it wants every load in flight at once
-        const long long i = blockIdx.x * (long long) kBlock + threadIdx.x;
-        bool strict = false, valid = i < n;
-        if (valid) {
-            const kr_ray_f64* ray = &rays[i];
-            const double k = ray->k, h = ray->h, Q = ray->Q, theta = ray->theta;
-            double sn, cs;
-            kr_sincos_f64(theta, sn, cs);
-            const double kac = k * a * cs;
-            const double hcs = h * cs / sn;
-            const double prod = (kac + hcs) * (kac - hcs);
-            const double sum = Q + prod;
-            strict = !(__builtin_fabs(sum) > 1e-9 * (__builtin_fabs(Q) + __builtin_fabs(prod))) || !(__builtin_fabs(h) >= 1e-13);
-        }
-        // wave-aggregated append to one of the two lists
-        const unsigned long long m_strict = __ballot(valid && strict), m_fast = __ballot(valid && !strict);
-        const int lane = threadIdx.x & 63;
-        const unsigned long long below = (1ull << lane) - 1;
-        unsigned long long base_s = 0, base_f = 0;
-        if (lane == 0) {
-            if (m_strict) base_s = atomicAdd(&counts[1], (unsigned long long) __popcll(m_strict));
-            if (m_fast) base_f = atomicAdd(&counts[0], (unsigned long long) __popcll(m_fast));
-        }
-        base_s = __shfl(base_s, 0, 64);
-        base_f = __shfl(base_f, 0, 64);
-        if (valid && strict) list_strict[base_s + __popcll(m_strict & below)] = (int) i;
-        if (valid && !strict) list_fast[base_f + __popcll(m_fast & below)] = (int) i;
+    // one ray per work-item: the pass is a 4-field gather over 144-byte records, so it wants every load in flight at once
+    const long long i = blockIdx.x * (long long) kBlock + threadIdx.x;
+    if (i >= n) return;
+    const kr_ray_f64* ray = &rays[i];
+    bool strict = false;
+    if (ray->steps >= 0) {                       // unused slots (steps == -1) are skipped by either launch
+        const double k = ray->k, h = ray->h, Q = ray->Q, theta = ray->theta;
+        double sn, cs;
+        kr_sincos_f64(theta, sn, cs);
+        const double kac = k * a * cs;
+        const double hcs = h * cs / sn;
+        const double prod = (kac + hcs) * (kac - hcs);
+        const double sum = Q + prod;
+        strict = !(__builtin_fabs(sum) > 1e-9 * (__builtin_fabs(Q) + __builtin_fabs(prod))) || !(__builtin_fabs(h) >= 1e-13);
     }
+    strict_mask[i] = strict ? 1 : 0;
+    // wave-aggregated append; ill-conditioned rays are rare (a column / a row of the source grid), so are the atomics
+    const unsigned long long m = __ballot(strict);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long) m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(n_strict, (unsigned long long) __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (strict) list_strict[base + __popcll(m & ((1ull << lane) - 1))] = (int) i;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -274,7 +272,7 @@ struct DeviceScratch {
     unsigned long long* counters = nullptr;      // 3 blocks of kCounters: main launch, side launch, {n_fast, n_strict}
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_classified = nullptr, ev_side_done = nullptr;
     hipStream_t side_stream = nullptr;
-    int* lists = nullptr;                        // 2 x capacity ray indices (hybrid path)
+    int* lists = nullptr;                        // hybrid path: capacity ray indices (strict list) + capacity mask bytes
     int64_t list_capacity = 0;
     int cus = 0;
 };
@@ -322,6 +320,7 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
 struct ListArgs {
     const int* list = nullptr;                    // ray indices, or null for 0 .. n
     const unsigned long long* n_ptr = nullptr;    // item count in device memory, or null (use n)
+    const unsigned char* skip = nullptr;          // per-ray "not mine" mask, or null
     int fixed_grid = 0;                           // > 0: launch exactly this many workgroups
 };
 
@@ -351,7 +350,7 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     const int64_t wanted = (n + kBlock - 1) / kBlock;
     int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
     if (la.fixed_grid > 0) grid = la.fixed_grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.skip);
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
@@ -381,31 +380,42 @@ int dispatch_hybrid(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim
         if (sc->lists) KR_HIP(hipFree(sc->lists));
         sc->lists = nullptr;
         sc->list_capacity = 0;
-        KR_HIP(hipMalloc((void**) &sc->lists, (size_t) 2 * (size_t) n * sizeof(int)));
+        KR_HIP(hipMalloc((void**) &sc->lists, (size_t) n * (sizeof(int) + 1)));
         sc->list_capacity = n;
     }
-    int* list_fast = sc->lists;
-    int* list_strict = sc->lists + n;
-    unsigned long long* counts = sc->counters + 2 * kCounters;     // [0] n_fast, [1] n_strict (zeroed by the caller's memset)
+    int* list_strict = sc->lists;
+    unsigned char* strict_mask = (unsigned char*) (sc->lists + n);
+    unsigned long long* counts = sc->counters + 2 * kCounters;     // [1] n_strict (zeroed by the caller's memset)
     const TraceConsts<double> c = make_consts<double>(p, steplim);
     const int mb = KR_FLAG_GET_BLOCKS_PER_CU(p->flags);
     const int cgrid = (int) ((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, list_fast, list_strict, counts);
+    hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, strict_mask, list_strict, counts + 1);
     KR_HIP(hipGetLastError());
+    // The split decides the launch geometry, so the host has to see it: one 8-byte read-back (~30 us against a >= 1 ms trace).
+    unsigned long long n_strict = 0;
+    KR_HIP(hipMemcpyAsync(&n_strict, counts + 1, sizeof(n_strict), hipMemcpyDeviceToHost, stream));
+    KR_HIP(hipStreamSynchronize(stream));
+    if (n_strict == 0) return launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, stream, mb, ListArgs());
+    if (n_strict > (unsigned long long) n / 8) {
+        // a source made mostly of ill-conditioned rays (e.g. all rays in one meridional plane): exclusive SIMDs for a few
+        // rays is the wrong shape -- everything goes through the strict kernel at its normal occupancy
+        const int rc = launch_f64<false, false>(p, rays, n, c, sc->counters, sc->cus, stream, mb, ListArgs());
+        return rc;
+    }
     KR_HIP(hipEventRecord(sc->ev_classified, stream));
     // The strict launch goes FIRST and on the caller's stream (right behind the classification, no cross-queue latency), so its
     // workgroups are placed while the chip is still empty; the fast launch arrives through the event on the side stream and
     // fills what is left.  (The other way round the fast launch takes every SIMD's registers and the strict one waits for it.)
+    // One workgroup (4 waves, each alone on its SIMD) per 256 strict rays, on at most half of the CUs.
     ListArgs strict_la;
     strict_la.list = list_strict;
     strict_la.n_ptr = counts + 1;
-    strict_la.fixed_grid = std::max(1, std::min(sc->cus / 8, 32));
+    strict_la.fixed_grid = (int) std::max<unsigned long long>(1, std::min<unsigned long long>((n_strict + kBlock - 1) / kBlock, (unsigned long long) sc->cus / 2));
     int rc = launch_f64<false, true>(p, rays, n, c, sc->counters + kCounters, sc->cus, stream, 1, strict_la);
     if (rc != KR_OK) return rc;
     KR_HIP(hipStreamWaitEvent(sc->side_stream, sc->ev_classified, 0));
     ListArgs fast_la;
-    fast_la.list = list_fast;
-    fast_la.n_ptr = counts;
+    fast_la.skip = strict_mask;
     rc = launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, sc->side_stream, mb ? mb : 3, fast_la);
     if (rc != KR_OK) return rc;
     KR_HIP(hipEventRecord(sc->ev_side_done, sc->side_stream));

@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $ROOT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-fast-math-extra $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || { echo trace failed; tail -5 $OUT/trace.err; exit 1; }
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py $ARGS > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.err || { echo pmc_sq failed; tail -5 $OUT/pmc_sq.err; }
 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d $OUT/pmc_grbm -- python3 bench.py $ARGS > $OUT/bench_pmc_grbm.json 2> $OUT/pmc_grbm.err || { echo pmc_grbm failed; tail -5 $OUT/pmc_grbm.err; }

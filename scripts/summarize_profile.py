@@ -11,14 +11,22 @@ summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats / --pmc <gro
 for d in sorted(glob.glob(f"{src}/pmc_*")):
     fs = glob.glob(f"{d}/*/*_counter_collection.csv")
     if not fs: continue
-    agg = collections.defaultdict(list); meta = {}
+    agg = collections.defaultdict(list); per = collections.defaultdict(lambda: collections.defaultdict(list)); meta = {}
     for row in csv.DictReader(open(fs[0])):
         if "trace_kernel" in row["Kernel_Name"]:
+            # hybrid mode runs two flavours per pass (fast main launch + strict register-hog side launch): sum them per pass
+            # for the whole-pass figures, and keep them apart under "per_kernel_variant"
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
-            meta = {"kernel": row["Kernel_Name"][:90], "grid": int(row["Grid_Size"]), "workgroup": int(row["Workgroup_Size"]), "vgpr": int(row["VGPR_Count"]), "sgpr": int(row["SGPR_Count"]), "lds": int(row["LDS_Block_Size"]), "scratch": int(row["Scratch_Size"])}
+            name = row["Kernel_Name"]
+            variant = name[name.index("trace_kernel"):name.index(">") + 1] if ">" in name else name[:60]
+            per[variant][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            meta[variant] = {"grid": int(row["Grid_Size"]), "workgroup": int(row["Workgroup_Size"]), "vgpr": int(row["VGPR_Count"]), "accum_vgpr": int(row.get("Accum_VGPR_Count", 0) or 0), "sgpr": int(row["SGPR_Count"]), "lds": int(row["LDS_Block_Size"]), "scratch": int(row["Scratch_Size"])}
+    nvar = max(1, len(per))
     for k, v in agg.items():
-        summary["counters_per_trace_kernel_launch"][k] = sum(v) / len(v)
-    if meta: summary.setdefault("dispatch", meta)
+        summary["counters_per_trace_kernel_launch"][k] = nvar * sum(v) / len(v)      # per pass = sum over the variants of one pass
+    for variant, d in per.items():
+        summary.setdefault("per_kernel_variant", {}).setdefault(variant, {}).update({k: sum(v) / len(v) for k, v in d.items()})
+        summary["per_kernel_variant"][variant]["dispatch"] = meta[variant]
 for f in sorted(glob.glob(f"{src}/bench_*.json")):
     try:
         b = json.loads(open(f).read().strip().splitlines()[-1])

@@ -367,3 +367,34 @@ def test_return_radiation_vs_oracle(krlib):
         # the GPU reducer on the CPU's rays agrees to summation order
         capi.check(lib, lib.kr_reduce_return_f64(C.byref(b), ol.ptr(want), len(want), C.byref(g4)), "reduce_return")
         np.testing.assert_allclose(np.array(g4), w, rtol=1e-12)
+
+
+# ---- hybrid mode is exactly "strict for the flagged rays, fast for the others" ------------------------------------
+def _same_bits(a, b):
+    return all(np.array_equal(a[f].view(np.uint8 if a[f].dtype.itemsize == 1 else f"u{a[f].dtype.itemsize}"),
+                              b[f].view(np.uint8 if b[f].dtype.itemsize == 1 else f"u{b[f].dtype.itemsize}")) for f in a.dtype.names)
+
+
+@pytest.mark.parametrize("method", [capi.RK4, capi.RK45])
+def test_hybrid_is_the_union_of_strict_and_fast(krlib, method):
+    g = np.load(gc.golden_path("ps_h10"))
+    init = g["init"]
+    p = capi.default_params(gc.SPIN)
+    p.integrator = method
+    strict, _ = api.trace(capi.copy_params(p, flags=0), init)
+    fast, _ = api.trace(capi.copy_params(p, flags=capi.FLAG_FAST_MATH), init)
+    hyb, st = api.trace(capi.copy_params(p, flags=capi.FLAG_HYBRID), init)
+    ke = parity.knife_edge_mask(init, False) & (init["steps"] >= 0)
+    assert st["rays_strict_side"] == int(ke.sum()) > 0              # the classifier finds exactly the beta = -pi / 0 columns
+    assert _same_bits(hyb[ke], strict[ke])
+    assert _same_bits(hyb[~ke], fast[~ke])
+    # no ill-conditioned ray: one fast launch, nothing on the side
+    clean = init[~ke]
+    h2, st2 = api.trace(capi.copy_params(p, flags=capi.FLAG_HYBRID), clean)
+    assert st2["rays_strict_side"] == 0 and _same_bits(h2, fast[~ke])
+    # mostly ill-conditioned rays (all in the meridional plane h = 0): everything takes the strict kernel
+    merid = init.copy()
+    merid["h"] = 0.0
+    s3, _ = api.trace(capi.copy_params(p, flags=0), merid)
+    h3, st3 = api.trace(capi.copy_params(p, flags=capi.FLAG_HYBRID), merid)
+    assert st3["rays_strict_side"] == int((merid["steps"] >= 0).sum()) and _same_bits(h3, s3)
