@@ -112,8 +112,15 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 // are left alone (they belong to the other launch of the hybrid path).  HOG: the kernel claims the whole register
 // file (512 VGPR+AGPR per lane), so each of its waves owns its SIMD and no other kernel's wave can be co-resident on
 // the CUs it occupies -- used for the few ill-conditioned / long rays that define the critical path.
+#ifndef KR_HOG_ATTR
+// HOG: the scheduler may trade registers for ILP.  Otherwise: RK4 must keep 3 waves per SIMD (<= 168 VGPRs), RK45 2.
+#ifndef KR_HOG_MAX_WAVES
+#define KR_HOG_MAX_WAVES 8   // measured: (1,1) makes the side launch 2 % slower
+#endif
+#define KR_HOG_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? 3 : METHOD == KR_RK45 ? 2 : 1, HOG ? KR_HOG_MAX_WAVES : 8)))
+#endif
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __launch_bounds__(kBlock, KR_MIN_WAVES)
+__global__ void __attribute__((amdgpu_flat_work_group_size(kBlock, kBlock))) KR_HOG_ATTR
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
              const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, const unsigned char* __restrict__ skip)
 {
