@@ -8,9 +8,12 @@
 #
 # Include resolution: the apps use `#include "../raytracer/imageplane.h"`-style paths, which a compiler
 # resolves relative to the including file first.  For (b) the source is therefore piped to the compiler on
-# stdin from inside raytrace_cpu_amd/host/raytracer/, so that `../raytracer/*.h` and `raytracer/*.h` find this
-# repo's headers while `../include/*.h` / `include/*.h` (par_file, text_output, fits_output, disc, array:
-# unchanged reference utilities) still come from the reference tree.  Nothing is copied.
+# stdin from inside raytrace_cpu_amd/host/raytracer/, so that `../raytracer/*.h`, `raytracer/*.h`, `../include/*.h` and
+# `include/*.h` all find this repo's headers: the class API mirror AND the utility headers (kerr, par_file, par_args,
+# text_output, fits_output, array, disc, gramschmidt_basis under raytrace_cpu_amd/host/include/).  The MI355X builds
+# therefore use nothing of the reference but each program's own main(), and do not link cfitsio (this repo's
+# fits_output.h writes the files itself); the reference tree stays on the include path only as a fallback for headers
+# this repo does not provide.  Nothing is copied.
 #
 # src/emissivity/emissivity.cpp does not compile as shipped (`disc_r + dr` is double* + double, line 79);
 # the same one-token fix that src/emissivity/emissivity_rd.cpp:88 carries is applied in the pipe for it.
@@ -36,7 +39,7 @@ build() {   # name  source  extra-flags  [sed-expression]
     ( cd $(dirname $src) && $feed | g++ $FLAGS $extra -I$REF/src -I$REF/src/raytracer -x c++ - -x none $REFLIB -o $CPUOUT/$name ${LINK:-} )
     # (b) this repo: headers from $HOST first, reference utilities second
     ( cd $HOST/raytracer && $feed | g++ $FLAGS $extra -I$HOST -I$REF/src -I$(dirname $src) -x c++ - -x none -o $GPUOUT/$name \
-        -L$HOST -lkr_host -L$ROOT/raytrace_cpu_amd/csrc -lkrtrace -Wl,-rpath,'$ORIGIN/../../raytrace_cpu_amd/host' -Wl,-rpath,'$ORIGIN/../../raytrace_cpu_amd/csrc' ${LINK:-} )
+        -L$HOST -lkr_host -L$ROOT/raytrace_cpu_amd/csrc -lkrtrace -Wl,-rpath,'$ORIGIN/../../raytrace_cpu_amd/host' -Wl,-rpath,'$ORIGIN/../../raytrace_cpu_amd/csrc' )
     echo "built $name"
 }
 

@@ -1,0 +1,74 @@
+// apps/app_common.h -- small helpers shared by the device-resident applications.
+#ifndef KR_APP_COMMON_H_
+#define KR_APP_COMMON_H_
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/kr_trace.h"
+
+namespace krapp {
+
+inline void check(int rc, const char* what)
+{
+    if (rc != KR_OK) throw std::runtime_error(std::string(what) + ": " + kr_last_error());
+}
+
+// KRTRACE_ARITHMETIC = hybrid (default) | strict | fast, as in the host mirror of the class API
+inline int arithmetic_flags(const std::string& choice)
+{
+    if (choice.empty() || choice == "hybrid") return KR_FLAG_HYBRID;
+    if (choice == "strict") return 0;
+    if (choice == "fast") return KR_FLAG_FAST_MATH;
+    throw std::invalid_argument("arithmetic: expected hybrid, strict or fast, got '" + choice + "'");
+}
+inline std::string arithmetic_from_env()
+{
+    const char* e = std::getenv("KRTRACE_ARITHMETIC");
+    return e ? std::string(e) : std::string();
+}
+
+inline int integrator_code(const std::string& name, int fallback)
+{
+    if (name == "euler") return KR_EULER;
+    if (name == "rk4") return KR_RK4;
+    if (name == "rk45") return KR_RK45;
+    return fallback;
+}
+
+// device buffer that frees itself
+class DeviceBuffer {
+public:
+    explicit DeviceBuffer(int64_t bytes) : bytes_(bytes) { check(kr_malloc(&ptr_, bytes), "kr_malloc"); }
+    ~DeviceBuffer() { if (ptr_) kr_free(ptr_); }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    void* get() const { return ptr_; }
+    void zero() { check(kr_memset(ptr_, 0, bytes_), "kr_memset"); }
+
+private:
+    void* ptr_ = nullptr;
+    int64_t bytes_;
+};
+
+class Stopwatch {
+public:
+    Stopwatch() : t0_(std::chrono::steady_clock::now()) {}
+    double lap_ms()
+    {
+        const auto t1 = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0_).count();
+        t0_ = t1;
+        return ms;
+    }
+
+private:
+    std::chrono::steady_clock::time_point t0_;
+};
+
+}   // namespace krapp
+
+#endif /* KR_APP_COMMON_H_ */

@@ -20,6 +20,9 @@ BUILD = os.path.join(gc.ROOT, "dropin", "_build")
 ENV = dict(os.environ, LD_PRELOAD="/usr/lib/x86_64-linux-gnu/libstdc++.so.6", LD_LIBRARY_PATH="/opt/conda/lib")
 
 
+COUNT_KEYS = {"DISC_N", "HIT_N", "ESC_N", "NHIT", "DISCRAYS"}     # header cards whose value may move by a chaotic ray
+
+
 def need(app):
     path = os.path.join(BUILD, app)
     if not os.path.exists(path):
@@ -63,8 +66,11 @@ def test_imageplane_app_matches_cpu_output(par):
         out = os.path.join(w, "out.fits")
         subprocess.run([exe, f"--parfile={os.path.join(APPS, par + '.par')}", f"--outfile={out}"], check=True, stdout=subprocess.DEVNULL, env=ENV, timeout=300)
         got = {h["name"]: h for h in fits_lite.read(out)}
+        got_cards = fits_lite.header_cards(out)
     want = {h["name"]: h for h in fits_lite.read(os.path.join(APPS, par + ".fits"))}
     assert list(got) == list(want) == ["PRIMARY", "FLUX", "RADIUS", "PHI", "ENSHIFT", "TIME", "EMIS"]
+    # the drop-in build writes the file with this repo's fits_output.h (no cfitsio): every header card identical to cfitsio's
+    assert got_cards == fits_lite.header_cards(os.path.join(APPS, par + ".fits"))
     for k in ("DIST", "INCL", "SPIN", "ISCO", "RDISC", "NRAYS", "DISCRAYS"):
         assert got["PRIMARY"]["header"][k] == want["PRIMARY"]["header"][k], k
     rtol = 1e-6 if par.endswith("rk4") else 1e-5     # RK45 per-ray noise envelope: tests/parity.py
@@ -103,8 +109,13 @@ def test_caustic_apps_match_cpu_output(par, app):
         out = os.path.join(w, "out.fits")
         subprocess.run([exe, f"--parfile={os.path.join(APPS, par + '.par')}", f"--outfile={out}"], check=True, stdout=subprocess.DEVNULL, env=ENV, timeout=600)
         got = {h["name"]: h for h in fits_lite.read(out)}
+        got_cards = fits_lite.header_cards(out)
     want = {h["name"]: h for h in fits_lite.read(os.path.join(APPS, par + ".fits"))}
     assert list(got) == list(want)
+    # headers written by this repo's fits_output.h vs cfitsio's: identical except for cards that carry a ray count
+    for gc_, wc_ in zip(got_cards, fits_lite.header_cards(os.path.join(APPS, par + ".fits"))):
+        diff = [(a, b) for a, b in zip(gc_, wc_) if a != b]
+        assert len(gc_) == len(wc_) and all(a[:8] == b[:8] and a[:8].strip() in COUNT_KEYS for a, b in diff), diff[:3]
     rk45 = par.endswith("rk45")
     for name in list(want)[1:]:
         g, w = got[name]["data"], want[name]["data"]
@@ -120,3 +131,61 @@ def test_caustic_apps_match_cpu_output(par, app):
         if name in ("PHI", "PHI_S"):                       # angles may differ by a 2 pi wrap on the branch cut
             close |= np.isclose(np.abs(g[ok] - w[ok]), 2 * np.pi, rtol=0, atol=1e-5)
         assert close.mean() >= need_frac, (name, close.mean())
+
+
+# ---- the device-resident applications (raytrace_cpu_amd/apps): same inputs, same output files ----------------------
+NATIVE = os.path.join(gc.ROOT, "raytrace_cpu_amd", "apps", "_build")
+
+
+def need_native(app):
+    path = os.path.join(NATIVE, app)
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not built (make -C raytrace_cpu_amd/apps)")
+    return path
+
+
+@pytest.mark.parametrize("arithmetic", ["hybrid", "strict"])
+def test_native_emissivity_app_matches_cpu_output(arithmetic):
+    exe = need_native("kr_emissivity")
+    with tempfile.TemporaryDirectory() as w:
+        out = os.path.join(w, "out.dat")
+        r = subprocess.run([exe, f"--parfile={os.path.join(APPS, 'emissivity.par')}", f"--outfile={out}", f"--arithmetic={arithmetic}", "--timing"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "timing: rays" in r.stdout
+        got_text = open(out).read()
+        rows = [l.split() for l in got_text.splitlines() if l.strip()]
+    got, want = np.array([[float(x) for x in r_] for r_ in rows]), load_dat("emissivity.dat")
+    want_text = open(os.path.join(APPS, "emissivity.dat")).read()
+    assert got.shape == want.shape
+    # columns 1-2 (radii, areas: host code) are the same TEXT as the reference's file
+    assert [l[:40] for l in got_text.splitlines()] == [l[:40] for l in want_text.splitlines()]
+    dcount = np.abs(got[:, 2] - want[:, 2])
+    assert dcount.max() <= 1
+    same = dcount == 0
+    for col in (3, 4, 5, 6):
+        g, w_ = got[same, col], want[same, col]
+        assert (np.isnan(g) == np.isnan(w_)).all()
+        ok = ~np.isnan(w_)
+        np.testing.assert_allclose(g[ok], w_[ok], rtol=1e-6, err_msg=f"column {col}")
+
+
+@pytest.mark.parametrize("par", ["imageplane_rk4", "imageplane_rk45"])
+def test_native_imageplane_app_matches_cpu_output(par):
+    exe = need_native("kr_imageplane_disc_image")
+    with tempfile.TemporaryDirectory() as w:
+        out = os.path.join(w, "out.fits")
+        r = subprocess.run([exe, f"--parfile={os.path.join(APPS, par + '.par')}", f"--outfile={out}"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = {h["name"]: h for h in fits_lite.read(out)}
+        got_cards = fits_lite.header_cards(out)
+        size = os.path.getsize(out)
+    golden = os.path.join(APPS, par + ".fits")
+    want = {h["name"]: h for h in fits_lite.read(golden)}
+    assert size == os.path.getsize(golden) and got_cards == fits_lite.header_cards(golden)      # every header byte, incl. DISCRAYS
+    rtol = 1e-6 if par.endswith("rk4") else 1e-5
+    for name in list(want)[1:]:
+        g, w_ = got[name]["data"], want[name]["data"]
+        assert (np.isnan(g) == np.isnan(w_)).all(), name
+        ok = ~np.isnan(w_)
+        np.testing.assert_allclose(g[ok], w_[ok], rtol=rtol, atol=1e-12, err_msg=name)
