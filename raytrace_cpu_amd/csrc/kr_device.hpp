@@ -243,16 +243,19 @@ KR_DEV double fast_rcp(double x)
     return y;
 }
 
-KR_DEV double fast_sqrt(double x)      // x >= 0 (callers pass |.|)
+KR_DEV double fast_sqrt(double x)      // sqrt(max(|x|, 1e-300)): rsq seed + one coupled Newton step + a residual correction
 {
+    // The floor replaces the x == 0 / x == inf special cases of a plain rsq-based root (5 instructions per call, 8 calls per
+    // RK4 step) by one v_max: a vanishing theta-dot or r-dot becomes 1e-150 instead of 0, which no later operation can tell
+    // apart (it is added to O(1) angles / radii, and its reciprocal only feeds step-size minima).  +inf gives NaN.
+    x = __builtin_fmax(__builtin_fabs(x), 1e-300);
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     const double e = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, e, g);
     h = __builtin_fma(h, e, h);
     const double d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
-    return (x == 0.0 || x == __builtin_inf()) ? x : g;
+    return __builtin_fma(d, h, g);
 }
 
 struct FastAux { double rhosq, sin2theta, inv_rhosq, sn, cs; };
@@ -307,11 +310,16 @@ KR_DEV void momentum_fast(double& pt, double& pr, double& ptheta, double& pphi, 
 #ifndef KR_STAGE_SINCOS_NEAR
 #define KR_STAGE_SINCOS_NEAR 1
 #endif
-KR_DEV void sincos_near(double theta0, double s0, double c0, double d, double& s, double& c)
+// largest |d| for which sincos_near() uses the angle addition from theta0 (computed once per step, shared by its stages)
+KR_DEV double sincos_near_limit(double theta0)
+{
+    return __builtin_fmin(0.125, 0.5 * __builtin_fmin(__builtin_fabs(theta0), __builtin_fabs(kPi - theta0)));
+}
+
+KR_DEV void sincos_near(double theta0, double s0, double c0, double d, double limit, double& s, double& c)
 {
 #pragma clang fp contract(fast)
-    const double ad = __builtin_fabs(d);
-    if (!KR_STAGE_SINCOS_NEAR || !(ad <= 0.125 && ad <= 0.5 * __builtin_fabs(theta0) && ad <= 0.5 * __builtin_fabs(kPi - theta0))) {
+    if (!KR_STAGE_SINCOS_NEAR || !(__builtin_fabs(d) <= limit)) {
         kr_sincos_f64(theta0 + d, s, c);
         return;
     }
@@ -338,7 +346,7 @@ KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
 #pragma clang fp contract(fast)
     const double r = s.r, theta = s.theta, k = s.k, h = s.h;
     double sn, c;
-    kr_sincos_f64(theta, sn, c);
+    kr_sincos_f64(theta, sn, c);   // (carrying sin/cos from step to step by angle addition was measured 6 % SLOWER: register pressure)
     const double s2 = sn * sn;
     const double ac = a * c;
     const double r2 = r * r;
@@ -534,10 +542,12 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     } else {
         // k2..k4 use k1's signs and move only (r, theta)  (:889-905)
         // stage evaluation; the fast path gets sin/cos of the stage angle from those of the base point
+        double near_limit = 0;
+        if constexpr (FAST) near_limit = sincos_near_limit(s.theta);
         auto stage = [&](T& pt, T& pr, T& ptheta, T& pphi, T r_stage, T dtheta) {
             if constexpr (FAST) {
                 double sn, cs;
-                sincos_near(s.theta, aux.sn, aux.cs, dtheta, sn, cs);
+                sincos_near(s.theta, aux.sn, aux.cs, dtheta, near_limit, sn, cs);
                 momentum_fast_sc(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, sn, cs, a);
             } else {
                 eval<T, false>(pt, pr, ptheta, pphi, s, r_stage, s.theta + dtheta, a);
