@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 3
+#define KR_ABI_VERSION 4
 
 /* error codes */
 #define KR_OK          0
@@ -267,6 +267,9 @@ int kr_debug_arith_f64(int op, const double* a, const double* b, double* out, in
 /* ---- device memory helpers for callers without a HIP runtime of their own --------------------- */
 int kr_malloc(void** d_ptr, int64_t bytes);
 int kr_free(void* d_ptr);
+/* page-locked host memory: kr_memcpy_* to / from it run at full PCIe rate without a staging copy or first-touch faults */
+int kr_host_alloc(void** h_ptr, int64_t bytes);
+int kr_host_free(void* h_ptr);
 int kr_memcpy_h2d(void* d_dst, const void* h_src, int64_t bytes);
 int kr_memcpy_d2h(void* h_dst, const void* d_src, int64_t bytes);
 int kr_memset(void* d_ptr, int value, int64_t bytes);

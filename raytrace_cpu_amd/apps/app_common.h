@@ -54,6 +54,27 @@ private:
     int64_t bytes_;
 };
 
+// page-locked host buffer of doubles (read-back target)
+class PinnedDoubles {
+public:
+    explicit PinnedDoubles(int64_t count) : count_(count)
+    {
+        void* p = nullptr;
+        check(kr_host_alloc(&p, count * (int64_t) sizeof(double)), "kr_host_alloc");
+        ptr_ = static_cast<double*>(p);
+    }
+    ~PinnedDoubles() { if (ptr_) kr_host_free(ptr_); }
+    PinnedDoubles(const PinnedDoubles&) = delete;
+    PinnedDoubles& operator=(const PinnedDoubles&) = delete;
+    double* data() const { return ptr_; }
+    int64_t size() const { return count_; }
+    double& operator[](int64_t i) const { return ptr_[i]; }
+
+private:
+    double* ptr_ = nullptr;
+    int64_t count_;
+};
+
 class Stopwatch {
 public:
     Stopwatch() : t0_(std::chrono::steady_clock::now()) {}

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -139,6 +139,8 @@ PROTOTYPES = {
     "kr_debug_arith_f64": (_int, [_int, _vp, _vp, _vp, _i64]),
     "kr_malloc": (_int, [P(_vp), _i64]),
     "kr_free": (_int, [_vp]),
+    "kr_host_alloc": (_int, [P(_vp), _i64]),
+    "kr_host_free": (_int, [_vp]),
     "kr_memcpy_h2d": (_int, [_vp, _vp, _i64]),
     "kr_memcpy_d2h": (_int, [_vp, _vp, _i64]),
     "kr_memset": (_int, [_vp, _int, _i64]),

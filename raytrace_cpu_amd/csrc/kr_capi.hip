@@ -442,6 +442,19 @@ int kr_free(void* d_ptr)
     KR_HIP(hipFree(d_ptr));
     return KR_OK;
 }
+int kr_host_alloc(void** h_ptr, int64_t bytes)
+{
+    if (!h_ptr || bytes < 0) { set_error("kr_host_alloc: bad argument"); return KR_EINVAL; }
+    int rc = require_device();
+    if (rc != KR_OK) return rc;
+    KR_HIP(hipHostMalloc(h_ptr, (size_t) (bytes ? bytes : 1), hipHostMallocDefault));
+    return KR_OK;
+}
+int kr_host_free(void* h_ptr)
+{
+    KR_HIP(hipHostFree(h_ptr));
+    return KR_OK;
+}
 int kr_memcpy_h2d(void* d_dst, const void* h_src, int64_t bytes)
 {
     KR_HIP(hipMemcpy(d_dst, h_src, (size_t) bytes, hipMemcpyHostToDevice));

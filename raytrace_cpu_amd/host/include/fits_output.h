@@ -178,32 +178,36 @@ public:
     // ------ images ------
     void write_image_array(double* frame, int Nx, int Ny)
     {
-        need_open();
-        cout << "Adding " << Nx << 'x' << Ny << " image extension to FITS file" << endl;
-        const long axes[2] = {Nx, Ny};
-        new_hdu(-64, axes, 2);
+        begin_image(Nx, Ny);
         const size_t n = static_cast<size_t>(Nx) * Ny;
-        data_.resize(n * 8);
-        for (size_t i = 0; i < n; ++i) {       // IEEE big-endian
-            uint64_t bits;
-            memcpy(&bits, &frame[i], 8);
-            for (int b = 0; b < 8; ++b) data_[i * 8 + b] = static_cast<char>((bits >> (56 - 8 * b)) & 0xff);
-        }
+        for (size_t i = 0; i < n; ++i) data_[i] = big_endian(frame[i]);
     }
 
     // data[x][y] -> image with X along FITS axis 1 (left to right) and Y along axis 2 (bottom to top); `transpose` swaps the
     // axes; flip_x / flip_y mirror the SOURCE array's axes
     void write_image(T** data, int Nx, int Ny, bool transpose = false, bool flip_x = false, bool flip_y = false)
     {
-        vector<double> frame(static_cast<size_t>(Nx) * Ny);
-        for (int j = 0; j < Nx; ++j)
-            for (int k = 0; k < Ny; ++k) {
-                const double v = data[flip_x ? Nx - 1 - j : j][flip_y ? Ny - 1 - k : k];
-                if (transpose) frame[static_cast<size_t>(j) * Ny + k] = v;
-                else frame[static_cast<size_t>(k) * Nx + j] = v;
+        if (transpose) {
+            begin_image(Ny, Nx);
+            for (int j = 0; j < Nx; ++j) {
+                const T* row = data[flip_x ? Nx - 1 - j : j];
+                uint64_t* out = &data_[static_cast<size_t>(j) * Ny];
+                for (int k = 0; k < Ny; ++k) out[k] = big_endian(static_cast<double>(row[flip_y ? Ny - 1 - k : k]));
             }
-        if (transpose) write_image_array(frame.data(), Ny, Nx);
-        else write_image_array(frame.data(), Nx, Ny);
+            return;
+        }
+        // out[k * Nx + j] = data[x(j)][y(k)] is a transposition: walk it in 32 x 32 tiles so that both sides stay in cache
+        begin_image(Nx, Ny);
+        constexpr int kTile = 32;
+        for (int j0 = 0; j0 < Nx; j0 += kTile)
+            for (int k0 = 0; k0 < Ny; k0 += kTile) {
+                const int j1 = j0 + kTile < Nx ? j0 + kTile : Nx, k1 = k0 + kTile < Ny ? k0 + kTile : Ny;
+                for (int j = j0; j < j1; ++j) {
+                    const T* row = data[flip_x ? Nx - 1 - j : j];
+                    for (int k = k0; k < k1; ++k)
+                        data_[static_cast<size_t>(k) * Nx + j] = big_endian(static_cast<double>(row[flip_y ? Ny - 1 - k : k]));
+                }
+            }
     }
 
     // one image extension per frame of data[frame][y][x], both axes mirrored (reference :190-207)
@@ -268,6 +272,23 @@ private:
         cards_.push_back(card);
     }
 
+    static uint64_t big_endian(double v)   // IEEE big-endian image of v as a word to be stored by a little-endian host
+    {
+        uint64_t bits;
+        memcpy(&bits, &v, 8);
+        return __builtin_bswap64(bits);
+    }
+
+    // a BITPIX = -64 image HDU of Nx x Ny pixels whose data_ the caller fills
+    void begin_image(int Nx, int Ny)
+    {
+        need_open();
+        cout << "Adding " << Nx << 'x' << Ny << " image extension to FITS file" << endl;
+        const long axes[2] = {Nx, Ny};
+        new_hdu(-64, axes, 2);
+        data_.assign(static_cast<size_t>(Nx) * Ny, 0);
+    }
+
     // mandatory cards of a new image HDU; the previous one goes to disk first
     void new_hdu(int bitpix, const long* axes, int naxis)
     {
@@ -308,8 +329,9 @@ private:
         const size_t used = cards_.size() * kf::kCard % kf::kBlock;
         if (used) file_ << string(kf::kBlock - used, ' ');
         if (!data_.empty()) {
-            file_.write(data_.data(), static_cast<streamsize>(data_.size()));
-            const size_t tail = data_.size() % kf::kBlock;
+            const size_t bytes = data_.size() * 8;
+            file_.write(reinterpret_cast<const char*>(data_.data()), static_cast<streamsize>(bytes));
+            const size_t tail = bytes % kf::kBlock;
             if (tail) file_ << string(kf::kBlock - tail, '\0');
         }
         cards_.clear();
@@ -320,7 +342,7 @@ private:
     bool open_ = false;
     int hdus_ = 0;
     vector<string> cards_;
-    vector<char> data_;
+    vector<uint64_t> data_;      // big-endian words of the current image
 };
 
 #endif /* FITS_OUTPUT_H_ */

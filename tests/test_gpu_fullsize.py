@@ -28,7 +28,8 @@ def _spec(d):
     return s
 
 
-def test_full_size_properties(krlib):
+@pytest.mark.parametrize("flags", [pytest.param(capi.FLAG_HYBRID, id="hybrid"), pytest.param(0, id="strict")])
+def test_full_size_properties(krlib, flags):
     lib = krlib
     spec = _spec(1.99 / (math.sqrt(1e7) - 1.0))
     n_beta = C.c_int32()
@@ -47,10 +48,11 @@ def test_full_size_properties(krlib):
         for k, i in enumerate(idx):
             capi.check(lib, lib.kr_memcpy_d2h(before[k:k + 1].ctypes.data_as(vp), vp(d_rays.value + int(i) * 144), 144), "d2h")
         p = capi.default_params(gc.SPIN)
-        p.integrator, p.r_max = capi.RK4, 1000.0
+        p.integrator, p.r_max, p.flags = capi.RK4, 1000.0, flags
         st = capi.Stats()
         capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, C.byref(st)), "trace")
         assert st.rays_traced > 9_990_000 and 4e9 < st.steps_total < 7e9
+        assert st.rays_strict_side == (3162 if flags else 0)      # hybrid: exactly the beta = -pi column (one ray per row)
         after = np.zeros(len(idx), dtype=capi.RAY_F64)
         for k, i in enumerate(idx):
             capi.check(lib, lib.kr_memcpy_d2h(after[k:k + 1].ctypes.data_as(vp), vp(d_rays.value + int(i) * 144), 144), "d2h")
