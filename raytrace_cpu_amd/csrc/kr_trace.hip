@@ -299,7 +299,16 @@ int scratch_for_current(DeviceScratch** out)
         KR_HIP(hipEventCreate(&sc.ev1));
         KR_HIP(hipEventCreateWithFlags(&sc.ev_classified, hipEventDisableTiming));
         KR_HIP(hipEventCreateWithFlags(&sc.ev_side_done, hipEventDisableTiming));
-        KR_HIP(hipStreamCreateWithFlags(&sc.side_stream, hipStreamNonBlocking));
+        {
+            // The side stream must not share a hardware queue with the caller's stream, or the two launches of the hybrid path
+            // serialise (seen once a process also holds RCCL's streams: HIP multiplexes streams onto a few queues per priority
+            // level).  A different priority level has queues of its own; the fast launch it carries is also the one that may wait.
+            int least = 0, greatest = 0;
+            KR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            int prio = least;
+            if (const char* e = getenv("KR_SIDE_STREAM_PRIORITY")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "default") ? 0 : least;
+            KR_HIP(hipStreamCreateWithPriority(&sc.side_stream, hipStreamNonBlocking, prio));
+        }
         hipDeviceProp_t prop;
         KR_HIP(hipGetDeviceProperties(&prop, dev));
         sc.cus = prop.multiProcessorCount;
