@@ -339,8 +339,6 @@ def main():
     wl = {"emissivity": EmissivityWorkload, "imageplane": ImagePlaneWorkload, "return_radiation": ReturnRadiationWorkload}[args.workload](args, lib, capi, api, rank, world)
     if args.fast_math:
         args.arithmetic = "fast"
-    if args.integrator == "euler" and args.arithmetic == "hybrid" and args.workload == "return_radiation":
-        pass                                             # hybrid applies to every integrator
     mode_flags = {"strict": 0, "hybrid": capi.FLAG_HYBRID, "fast": capi.FLAG_FAST_MATH}
     mode_mask = capi.FLAG_HYBRID | capi.FLAG_FAST_MATH
     wl.p.flags = (wl.p.flags & ~mode_mask) | mode_flags[args.arithmetic]

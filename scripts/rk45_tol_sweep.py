@@ -9,8 +9,9 @@ import numpy as np
 import golden_cases as gc
 from raytrace_cpu_amd import api, capi
 
+ARITH = {"hybrid": capi.FLAG_HYBRID, "strict": 0, "fast": capi.FLAG_FAST_MATH}[sys.argv[1] if len(sys.argv) > 1 else "hybrid"]
 TOLS = [1e-6, 3e-7, 1e-7, 3e-8, 1e-8, 3e-9, 1e-9, 3e-10, 1e-10]
-out = {"grid": "dcosalpha = dbeta = 0.01, cos(alpha) in [-0.995, 0.995), beta in [-pi, pi)", "device": api.device_info(), "runs": []}
+out = {"arithmetic": sys.argv[1] if len(sys.argv) > 1 else "hybrid", "grid": "dcosalpha = dbeta = 0.01, cos(alpha) in [-0.995, 0.995), beta in [-pi, pi)", "device": api.device_info(), "runs": []}
 for h in (5.0, 10.0):
     spec = capi.PointSourceSpec()
     for i, v in enumerate([0.0, h, 1e-3, 0.0]): spec.pos[i] = v
@@ -21,7 +22,7 @@ for h in (5.0, 10.0):
     api.redshift_start(gc.SPIN, 0.0, 0, 0, init)
     bins = gc.emis_bins(spec, nr=30)
     def run(method, tol):
-        p = capi.default_params(gc.SPIN); p.integrator, p.rk45_tol = method, tol
+        p = capi.default_params(gc.SPIN); p.integrator, p.rk45_tol, p.flags = method, tol, ARITH
         best = None
         for _ in range(2):
             rays, st = api.trace(p, init)
