@@ -4,10 +4,22 @@ src/tests/emissivity_rk45_plot.cpp:35-38 grid 0.01 x 0.01 = 125 863 allocated ra
 sweep) and h = 10 (BASELINE), on one MI355X through the C ABI.  Prints one JSON document.
 RK4 on the same grid is run beside it so the RK4-vs-RK45 emissivity deviation the reference's sweep plots can be formed."""
 import json, math, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
-import golden_cases as gc
+import bench
 from raytrace_cpu_amd import api, capi
+
+
+class gc:                                   # the constants this sweep shares with the benchmark
+    SPIN = bench.SPIN
+
+    @staticmethod
+    def emis_bins(spec, nr):
+        n_primary = int(((spec.cosalphamax - spec.cosalpha0) / spec.dcosalpha) * ((spec.betamax - spec.beta0) / spec.dbeta))
+        b = bench.emis_bins(capi, api.lib().kr_kerr_isco(bench.SPIN, 1), n_primary)
+        b.dr = math.exp(math.log(bench.R_DISC / b.r_min) / nr)
+        b.nr = nr
+        return b
 
 ARITH = {"hybrid": capi.FLAG_HYBRID, "strict": 0, "fast": capi.FLAG_FAST_MATH}[sys.argv[1] if len(sys.argv) > 1 else "hybrid"]
 TOLS = [1e-6, 3e-7, 1e-7, 3e-8, 1e-8, 3e-9, 1e-9, 3e-10, 1e-10]
