@@ -48,10 +48,13 @@ build emissivity            $REF/src/emissivity/emissivity.cpp    "" 's/disc_r[[
 build raytrace_rk4_test     $REF/src/tests/raytrace_rk4_test.cpp  ""
 build emissivity_rk45_test  $REF/src/tests/emissivity_rk45_test.cpp ""
 build integrator_perf_test  $REF/src/tests/integrator_perf_test.cpp ""
+build emissivity_rk45_plot  $REF/src/tests/emissivity_rk45_plot.cpp ""
 if [ -f $CFITS_INC/fitsio.h ]; then
     # link cfitsio by path: -L$CFITS_LIB would also pull conda's (older) libstdc++ ahead of the system one that
     # libamdhip64 needs.  Run the binaries with LD_PRELOAD=<system libstdc++.so.6> LD_LIBRARY_PATH=$CFITS_LIB.
-    LINK="$CFITS_LIB/libcfitsio.so" build imageplane_disc_image $REF/src/imageplane/imageplane_disc_image.cpp "-fpermissive -I$CFITS_INC"
+    for app in imageplane_disc_image imageplane_disc_image_isco imageplane_disc_image_rd; do
+        LINK="$CFITS_LIB/libcfitsio.so" build $app $REF/src/imageplane/$app.cpp "-fpermissive -I$CFITS_INC"
+    done
     for app in caustic_discplane caustic_sourceplane caustic_plane; do
         LINK="$CFITS_LIB/libcfitsio.so" build $app $REF/src/caustic/$app.cpp "-fpermissive -I$CFITS_INC"
     done

@@ -13,6 +13,13 @@ W=$(mktemp -d); mkdir -p $W/par $W/run
 cp $G/emissivity.par $G/emissivity_rd.par $W/par/
 ( cd $W/run && $APPS/emissivity --outfile=$G/emissivity.dat > /dev/null && $APPS/emissivity_rd --outfile=$G/emissivity_rd.dat > /dev/null )
 rm -rf $W
+# imageplane_disc_image_rd.cpp has the same dangling --parfile pointer (:42-50): default path from a scratch dir
+W=$(mktemp -d); mkdir -p $W/par $W/run
+cp $G/imageplane_rd.par $W/par/imageplane_disc_image_rd.par
+rm -f $G/imageplane_rd.fits $G/imageplane_isco.fits
+( cd $W/run && $APPS/imageplane_disc_image_rd --outfile=$G/imageplane_rd.fits > /dev/null )
+rm -rf $W
+$APPS/imageplane_disc_image_isco --parfile=$G/imageplane_isco.par --outfile=$G/imageplane_isco.fits > /dev/null
 rm -f $G/imageplane_rk4.fits $G/imageplane_rk45.fits
 $APPS/imageplane_disc_image --parfile=$G/imageplane_rk4.par  --outfile=$G/imageplane_rk4.fits  > /dev/null
 $APPS/imageplane_disc_image --parfile=$G/imageplane_rk45.par --outfile=$G/imageplane_rk45.fits > /dev/null
@@ -21,6 +28,8 @@ for c in caustic_discplane caustic_discplane_rk45 caustic_sourceplane; do
     app=${c%_rk45}
     $APPS/$app --parfile=$G/$c.par --outfile=$G/$c.fits > /dev/null
 done
+# BASELINE configs[2]: one point (tol = 1e-8) of the RK45 tolerance sweep, src/tests/emissivity_rk45_plot.cpp
+$APPS/emissivity_rk45_plot $G/emissivity_rk45_plot.csv 1e-8 > /dev/null
 $APPS/raytrace_rk4_test    | tail -16 > $G/raytrace_rk4_test.txt
 $APPS/emissivity_rk45_test | tail -40 > $G/emissivity_rk45_test.txt
 ls -la $G

@@ -81,6 +81,51 @@ def test_imageplane_app_matches_cpu_output(par):
         np.testing.assert_allclose(g[ok], w[ok], rtol=rtol, atol=1e-12, err_msg=name)
 
 
+@pytest.mark.parametrize("par,app", [("imageplane_isco", "imageplane_disc_image_isco"), ("imageplane_rd", "imageplane_disc_image_rd")])
+def test_imageplane_destination_apps_match_cpu_output(par, app):
+    """src/imageplane/imageplane_disc_image_isco.cpp (DiscWithISCODestination) and imageplane_disc_image_rd.cpp
+    (FlatDiscDestination + redshift through the destination's four-velocity), unmodified, on the HIP path."""
+    exe = need(app)
+    with tempfile.TemporaryDirectory() as w:
+        out = os.path.join(w, "out.fits")
+        if app.endswith("_rd"):     # same dangling --parfile pointer as the emissivity programs: use the built-in default path
+            os.makedirs(os.path.join(w, "par"))
+            os.makedirs(os.path.join(w, "run"))
+            shutil.copy(os.path.join(APPS, par + ".par"), os.path.join(w, "par", app + ".par"))
+            subprocess.run([exe, f"--outfile={out}"], cwd=os.path.join(w, "run"), check=True, stdout=subprocess.DEVNULL, env=ENV, timeout=300)
+        else:
+            subprocess.run([exe, f"--parfile={os.path.join(APPS, par + '.par')}", f"--outfile={out}"], check=True, stdout=subprocess.DEVNULL, env=ENV, timeout=300)
+        got = {h["name"]: h for h in fits_lite.read(out)}
+        got_cards = fits_lite.header_cards(out)
+    golden = os.path.join(APPS, par + ".fits")
+    want = {h["name"]: h for h in fits_lite.read(golden)}
+    assert list(got) == list(want) and got_cards == fits_lite.header_cards(golden)
+    for name in list(want)[1:]:
+        g, w_ = got[name]["data"], want[name]["data"]
+        assert (np.isnan(g) == np.isnan(w_)).all(), name
+        ok = ~np.isnan(w_)
+        np.testing.assert_allclose(g[ok], w_[ok], rtol=1e-6, atol=1e-12, err_msg=name)
+
+
+def test_rk45_tolerance_sweep_program_matches_cpu_output():
+    """BASELINE configs[2]: src/tests/emissivity_rk45_plot.cpp (one point of the tolerance sweep: RK4 and RK45 emissivity
+    profiles of the same 125 863-slot grid, 22 s on the build container's CPUs), unmodified, on the HIP path."""
+    exe = need("emissivity_rk45_plot")
+    with tempfile.TemporaryDirectory() as w:
+        out = os.path.join(w, "out.csv")
+        subprocess.run([exe, out, "1e-8"], check=True, stdout=subprocess.DEVNULL, env=ENV, timeout=600)
+        got_lines = open(out).read().splitlines()
+    want_lines = open(os.path.join(APPS, "emissivity_rk45_plot.csv")).read().splitlines()
+    assert got_lines[:2] == want_lines[:2] and len(got_lines) == len(want_lines)
+    got = np.array([[float(x) for x in l.split()] for l in got_lines[2:]])
+    want = np.array([[float(x) for x in l.split()] for l in want_lines[2:]])
+    assert (got[:, 0] == want[:, 0]).all()
+    assert np.abs(got[:, 1] - want[:, 1]).max() <= 1 and np.abs(got[:, 2] - want[:, 2]).max() <= 2      # ray counts: RK4, RK45
+    same4, same45 = got[:, 1] == want[:, 1], got[:, 2] == want[:, 2]
+    for col, same, rtol in ((3, same4, 1e-6), (5, same4, 1e-6), (7, same4, 1e-6), (4, same45, 1e-5), (6, same45, 1e-5), (8, same45, 1e-5)):
+        np.testing.assert_allclose(got[same, col], want[same, col], rtol=rtol, err_msg=f"column {col}")
+
+
 def test_reference_self_tests_pass_on_the_hip_path():
     """src/tests/raytrace_rk4_test.cpp and emissivity_rk45_test.cpp, built against the HIP path, still PASS and
     report the same classification counts as their CPU runs."""
