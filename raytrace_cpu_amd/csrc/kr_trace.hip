@@ -333,6 +333,8 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
     return c;
 }
 
+constexpr int64_t kIsolateMinRays = 1 << 18;      // below this a strict launch is too short for the split to pay
+
 struct ListArgs {
     const int* list = nullptr;                    // ray indices, or null for 0 .. n
     const unsigned long long* n_ptr = nullptr;    // item count in device memory, or null (use n)
@@ -388,8 +390,10 @@ int launch_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, const TraceConst
     }
 }
 
-// KR_FLAG_HYBRID: classify -> [side stream] strict HOG launch over the ill-conditioned rays  ||  [stream] fast launch over the rest
-int dispatch_hybrid(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, DeviceScratch* sc, hipStream_t stream)
+// classify -> strict HOG launch over the ill-conditioned rays (caller's stream)  ||  main launch over the rest (side stream).
+// fast_main: the main launch uses the fast arithmetic (KR_FLAG_HYBRID); otherwise it is the strict kernel too, i.e. the
+// results are those of one strict launch, bit for bit, and only the placement of the long rays differs.
+int dispatch_split(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, DeviceScratch* sc, hipStream_t stream, bool fast_main)
 {
     if (n > 0x7fffffff) { set_error("kr_trace: hybrid path indexes rays with 32 bits"); return KR_EINVAL; }
     if (sc->list_capacity < n) {
@@ -411,7 +415,9 @@ int dispatch_hybrid(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim
     unsigned long long n_strict = 0;
     KR_HIP(hipMemcpyAsync(&n_strict, counts + 1, sizeof(n_strict), hipMemcpyDeviceToHost, stream));
     KR_HIP(hipStreamSynchronize(stream));
-    if (n_strict == 0) return launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, stream, mb, ListArgs());
+    if (n_strict == 0)
+        return fast_main ? launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, stream, mb, ListArgs())
+                         : launch_f64<false, false>(p, rays, n, c, sc->counters, sc->cus, stream, mb, ListArgs());
     if (n_strict > (unsigned long long) n / 8) {
         // a source made mostly of ill-conditioned rays (e.g. all rays in one meridional plane): exclusive SIMDs for a few
         // rays is the wrong shape -- everything goes through the strict kernel at its normal occupancy
@@ -432,7 +438,8 @@ int dispatch_hybrid(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim
     KR_HIP(hipStreamWaitEvent(sc->side_stream, sc->ev_classified, 0));
     ListArgs fast_la;
     fast_la.skip = strict_mask;
-    rc = launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, sc->side_stream, mb ? mb : 3, fast_la);
+    rc = fast_main ? launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, sc->side_stream, mb ? mb : 3, fast_la)
+                   : launch_f64<false, false>(p, rays, n, c, sc->counters, sc->cus, sc->side_stream, mb ? mb : 3, fast_la);
     if (rc != KR_OK) return rc;
     KR_HIP(hipEventRecord(sc->ev_side_done, sc->side_stream));
     KR_HIP(hipStreamWaitEvent(stream, sc->ev_side_done, 0));
@@ -498,9 +505,12 @@ int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, k
     KR_HIP(hipMemsetAsync(sc->counters, 0, 3 * kCounters * sizeof(unsigned long long), stream));
     if (stats) KR_HIP(hipEventRecord(sc->ev0, stream));
     const bool hybrid = !f32 && (p->flags & KR_FLAG_HYBRID) && !(p->flags & KR_FLAG_FAST_MATH);
+    // all-strict launches of some size isolate their ill-conditioned (in the lamp-post workloads: longest) rays the same way:
+    // identical results, no tail.  KR_NO_ISOLATE=1 keeps the single launch (A/B and bit-identity tests).
+    const bool isolate = !f32 && !hybrid && !(p->flags & KR_FLAG_FAST_MATH) && n >= kIsolateMinRays && !getenv("KR_NO_ISOLATE");
     rc = f32 ? dispatch<float>(p, d_rays, n, steplim, sc->counters, sc->cus, stream)
-             : hybrid ? dispatch_hybrid(p, (kr_ray_f64*) d_rays, n, steplim, sc, stream)
-                      : dispatch<double>(p, d_rays, n, steplim, sc->counters, sc->cus, stream);
+             : (hybrid || isolate) ? dispatch_split(p, (kr_ray_f64*) d_rays, n, steplim, sc, stream, hybrid)
+                                   : dispatch<double>(p, d_rays, n, steplim, sc->counters, sc->cus, stream);
     if (rc != KR_OK) return rc;
     if (stats) {
         KR_HIP(hipEventRecord(sc->ev1, stream));

@@ -52,7 +52,7 @@ def test_full_size_properties(krlib, flags):
         st = capi.Stats()
         capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, C.byref(st)), "trace")
         assert st.rays_traced > 9_990_000 and 4e9 < st.steps_total < 7e9
-        assert st.rays_strict_side == (3162 if flags else 0)      # hybrid: exactly the beta = -pi column (one ray per row)
+        assert st.rays_strict_side == 3162      # either way exactly the beta = -pi column (one ray per row) goes to the side launch
         after = np.zeros(len(idx), dtype=capi.RAY_F64)
         for k, i in enumerate(idx):
             capi.check(lib, lib.kr_memcpy_d2h(after[k:k + 1].ctypes.data_as(vp), vp(d_rays.value + int(i) * 144), 144), "d2h")

@@ -398,3 +398,20 @@ def test_hybrid_is_the_union_of_strict_and_fast(krlib, method):
     s3, _ = api.trace(capi.copy_params(p, flags=0), merid)
     h3, st3 = api.trace(capi.copy_params(p, flags=capi.FLAG_HYBRID), merid)
     assert st3["rays_strict_side"] == int((merid["steps"] >= 0).sum()) and _same_bits(h3, s3)
+
+
+def test_strict_launch_split_is_bitwise_neutral(krlib, monkeypatch):
+    """Large all-strict launches put their ill-conditioned rays on the side launch as well (kr_trace.hip: kIsolateMinRays);
+    that changes where rays run, never what is computed: same bits as the single launch (KR_NO_ISOLATE=1)."""
+    import bench
+    spec = bench.make_spec(capi, bench.grid_spacing_for(3.2e5))
+    init = api.pointsource_init(spec)
+    api.redshift_start(gc.SPIN, 0.0, 0, 0, init)
+    assert len(init) >= (1 << 18)
+    p = capi.default_params(gc.SPIN)
+    p.integrator, p.r_max = capi.RK4, 1000.0
+    split, st_split = api.trace(p, init)
+    monkeypatch.setenv("KR_NO_ISOLATE", "1")
+    single, st_single = api.trace(p, init)
+    assert st_split["rays_strict_side"] > 0 and st_single["rays_strict_side"] == 0
+    assert st_split["steps_total"] == st_single["steps_total"] and _same_bits(split, single)
