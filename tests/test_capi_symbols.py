@@ -71,3 +71,30 @@ def test_no_cpu_fallback_without_gpu(lib):
     assert b"no HIP device" in lib.kr_last_error()
     assert lib.kr_redshift_f64(0.998, -1.0, 0, 0, 0, rays.ctypes.data_as(C.c_void_p), 8) == capi.KR_ENODEVICE
     assert (rays["r"] == 0).all()
+
+
+def test_host_mirror_fails_loudly_without_gpu():
+    """The C++ mirror of the reference class API has no CPU integration loop: on a box without a GPU run_raytrace() ends in
+    an exception that names the reason (it must never return silently with untraced rays)."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "tests", "cpp", "host_api_test")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.parametrize("app,par", [("kr_emissivity", "emissivity.par"), ("kr_imageplane_disc_image", "imageplane_rk4.par")])
+def test_device_resident_programs_fail_loudly_without_gpu(app, par, tmp_path):
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "raytrace_cpu_amd", "apps")], check=True)
+    exe = os.path.join(ROOT, "raytrace_cpu_amd", "apps", "_build", app)
+    out = tmp_path / "out"
+    r = subprocess.run([exe, f"--parfile={os.path.join(ROOT, 'tests', 'golden', 'apps', par)}", f"--outfile={out}"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device available" in r.stderr and not out.exists()
