@@ -459,6 +459,7 @@ def cpu_baseline_imageplane(args, capi, api, wl):
     if kind == "reference":
         src = ol.RefSource(spec)
         src.lib.ref_redshift_start(src.h, 0.0, 1, 0)
+        init = src.snapshot()
         t0 = time.perf_counter()
         src.run(p)
         wall = time.perf_counter() - t0
@@ -472,8 +473,41 @@ def cpu_baseline_imageplane(args, capi, api, wl):
         wall = time.perf_counter() - t0
     live = out["steps"] != -1
     steps = int(np.abs(out["steps"][live].astype(np.int64)).sum())
+    # parity of the image planes on this sample: GPU (same init rays, headline arithmetic, through the C ABI) vs CPU
+    o = ol.oracle()
+    o.kro_redshift_f64(-SPIN, -1.0, 1, 0, 0, ol.ptr(out), len(out))
+    o.kro_range_phi_f64(-math.pi, math.pi, ol.ptr(out), len(out))
+    img = 256
+    b = capi.ImageBins()
+    b.x0, b.y0, b.img_dx, b.img_dy = -30.0, -30.0, 60.0 / img, 60.0 / img
+    b.r_isco, b.r_disc = wl.bins.r_isco, wl.bins.r_disc
+    b.q1, b.rb1, b.q2, b.rb2, b.q3 = wl.bins.q1, wl.bins.rb1, wl.bins.q2, wl.bins.rb2, wl.bins.q3
+    b.img_nx, b.img_ny, b.flip_image, b.pad = img, img, 1, 0
+    npix = img * img
+    w_n = np.zeros(npix, dtype=np.int32)
+    keys = ("flux", "r", "phi", "enshift", "time", "emis")
+    w_pl = {k: np.zeros(npix) for k in keys}
+    dc = C.c_int64()
+    o.kro_reduce_image_f64(C.byref(b), ol.ptr(out), len(out), ol.ptr(w_n), *[ol.ptr(w_pl[k]) for k in keys], C.byref(dc))
+    gpu, _ = api.trace(p, init)
+    api.redshift(-SPIN, -1.0, 1, 0, gpu)
+    api.range_phi(gpu)
+    got = api.reduce_image(b, gpu)
+    same = got["nrays"] == w_n
+    worst = {}
+    for k in ("r", "enshift", "flux", "time"):
+        m = same & (w_n > 0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            worst[k] = float(np.max(np.abs(got[k][m] - w_pl[k][m]) / np.abs(w_pl[k][m]))) if m.any() else 0.0
+    ints_differ = 0
+    for k in ("status", "rdot_flips", "equatorial_crossings", "steps"):
+        ints_differ += int((gpu[k] != out[k]).sum())
+    planes_check = {"image": f"{img}x{img}", "lit_pixels": int((w_n > 0).sum()), "pixels_count_mismatch": int((~same).sum()), "disc_rays_cpu": int(dc.value),
+                    "disc_rays_gpu": int(got["disc_count"]), "max_rel_diff_of_pixel_sums(RADIUS, ENSHIFT, FLUX, TIME)": worst, "tolerance": 1e-6,
+                    "ray_integer_fields_differ": ints_differ}
     return {"value": int(live.sum()) / wall, "unit": "rays/s", "cores": cores, "kind": kind, "steps_per_sec": steps / wall, "wall_s": wall,
-            "sample": f"same image plane on a {N + 1}x{N + 1} ray grid: {int(live.sum())} rays, {steps} steps, run_raytrace only"}
+            "sample": f"same image plane on a {N + 1}x{N + 1} ray grid: {int(live.sum())} rays, {steps} steps, run_raytrace only",
+            "planes_check": planes_check}
 
 
 if __name__ == "__main__":
