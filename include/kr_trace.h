@@ -62,14 +62,21 @@ extern "C" {
 #define KR_STATUS_NAN         (1 << 6)
 
 /* kr_params.flags */
-#define KR_FLAG_FAST_MATH     (1 << 0)  /* f64 trace only: same formulas with shared reciprocals, Newton-refined rcp/rsq and FMA
-                                           contraction instead of IEEE division/sqrt (a few ulp per operation; ~1.4x faster).
-                                           0 = strict: the reference's association with IEEE + - * / sqrt, no contraction. */
+#define KR_FLAG_FAST_MATH     (1 << 0)  /* f64 trace only: same formulas with shared reciprocals, Newton-refined rcp/rsq, FMA
+                                           contraction and stage sin/cos by angle addition instead of IEEE division/sqrt and one
+                                           sincos per evaluation (a few ulp per operation; ~1.6x faster).  Rays whose outcome is
+                                           rounding-decided in the reference may end differently: prefer KR_FLAG_HYBRID.
+                                           0 = strict: the reference's association with IEEE + - * / sqrt, no contraction.  (A strict
+                                           launch of >= 2^18 rays also puts its ill-conditioned rays on a side launch -- see HYBRID --
+                                           which changes where they run, never their bits; env KR_NO_ISOLATE=1 disables that.) */
 
 #define KR_FLAG_HYBRID        (1 << 1)  /* f64 trace only: rays whose polar motion / axial angular momentum is a cancellation residue
                                            (their outcome in the reference is decided by rounding) and NaN rays are integrated on
                                            the strict path, in a side launch whose waves own their SIMDs; all other rays take the
-                                           fast-math path.  Reproduces the reference on every ray class at ~1.5x the strict speed. */
+                                           fast-math path.  Reproduces the reference on every ray class at ~1.4x the strict speed.
+                                           The call synchronises `stream` once (an 8-byte read-back sizes the side launch) and
+                                           uses a second, internal stream of its own priority level for the concurrent launch.
+                                           Ignored by the f32 entry points and when KR_FLAG_FAST_MATH is set. */
 #define KR_FLAG_BLOCKS_PER_CU(n)      (((n) & 0xF) << 8)   /* resident 256-thread workgroups per CU for the trace kernel, 0 = default (2) */
 #define KR_FLAG_GET_BLOCKS_PER_CU(f)  (((f) >> 8) & 0xF)
 
@@ -130,7 +137,8 @@ typedef struct kr_stats {
     int64_t rk45_rejects;    /* RK45: trial steps rejected */
     double  kernel_ms;       /* trace kernel duration, HIP events on the launch stream */
     double  h2d_ms, d2h_ms;  /* host-buffer entry points only */
-    int64_t rays_strict_side;       /* KR_FLAG_HYBRID: rays classified ill-conditioned and traced by the strict side launch */
+    int64_t rays_strict_side;       /* rays classified ill-conditioned and traced by the strict side launch (KR_FLAG_HYBRID, and
+                                       strict launches of >= 2^18 rays); 0 when the trace was a single launch */
     int64_t rk45_stationary_steps;  /* RK45: steps (included in steps_total and rk45_attempts) that were replayed as bare t/phi
                                        additions after a captured ray reached an exact fp64 fixed point in (r, theta, step);
                                        bit-identical to iterating them (kr_device.hpp::step_rk45) */
