@@ -1,6 +1,5 @@
 #!/bin/bash
-# GPU box: trace-kernel time vs resident workgroups per CU (KR_BLOCKS_PER_CU), emissivity RK4
-for rays in 3e6 1e7; do for b in 1 2 3; do
-  echo -n "rays=$rays blocks_per_cu=$b  "
-  KR_BLOCKS_PER_CU=$b python bench.py --steps 3 --warmup 1 --no-cpu-baseline --rays $rays 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('kernel_ms %.1f steps/s %.3e' % (d['roofline']['avg_kernel_ms'], d['roofline']['kernel_steps_per_sec']))"
-done; done
+run() { python bench.py --steps 3 --warmup 1 --no-cpu-baseline $2 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1 kernel_ms %.1f steps/s %.3e ms_per_step %.1f' % (d['roofline']['avg_kernel_ms'], d['roofline']['kernel_steps_per_sec'], d['ms_per_step']))"; }
+for b in 1 2 3; do KR_BLOCKS_PER_CU=$b run "strict b$b" "--arithmetic strict"; done
+for b in 1 2 3; do KR_BLOCKS_PER_CU=$b run "fast b$b" --arithmetic fast; done
+for b in 2 3; do KR_BLOCKS_PER_CU=$b run "strict 3e7 b$b" "--rays 3e7"; done
