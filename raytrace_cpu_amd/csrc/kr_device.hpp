@@ -316,13 +316,9 @@ KR_DEV double sincos_near_limit(double theta0)
     return __builtin_fmin(0.125, 0.5 * __builtin_fmin(__builtin_fabs(theta0), __builtin_fabs(kPi - theta0)));
 }
 
-KR_DEV void sincos_near(double theta0, double s0, double c0, double d, double limit, double& s, double& c)
+KR_DEV void sincos_near(double s0, double c0, double d, double& s, double& c)   // valid for |d| <= sincos_near_limit(theta0)
 {
 #pragma clang fp contract(fast)
-    if (!KR_STAGE_SINCOS_NEAR || !(__builtin_fabs(d) <= limit)) {
-        kr_sincos_f64(theta0 + d, s, c);
-        return;
-    }
     const double d2 = d * d;
     double ps = -1.0 / 39916800.0;
     ps = __builtin_fma(ps, d2, 1.0 / 362880.0);
@@ -542,27 +538,48 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     } else {
         // k2..k4 use k1's signs and move only (r, theta)  (:889-905)
         // stage evaluation; the fast path gets sin/cos of the stage angle from those of the base point
+        // Stages 2-4.  Fast path: sin/cos of the stage angles come from the base point's by angle addition, which is valid
+        // while every stage stays within near_limit of it -- practically always.  The stages are therefore computed
+        // optimistically, branch-free, and in the rare other case all three are redone with the full routine (one branch
+        // per step instead of one per stage; nothing of `s` has been touched yet).
         double near_limit = 0;
         if constexpr (FAST) near_limit = sincos_near_limit(s.theta);
-        auto stage = [&](T& pt, T& pr, T& ptheta, T& pphi, T r_stage, T dtheta) {
-            if constexpr (FAST) {
-                double sn, cs;
-                sincos_near(s.theta, aux.sn, aux.cs, dtheta, near_limit, sn, cs);
-                momentum_fast_sc(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, sn, cs, a);
-            } else {
-                eval<T, false>(pt, pr, ptheta, pphi, s, r_stage, s.theta + dtheta, a);
-            }
+        T acc_t, acc_phi, acc_r, acc_theta, pt4, pr4, ptheta4, pphi4;
+        auto stages = [&](auto near) -> bool {
+            constexpr bool kNear = decltype(near)::value;
+            bool within = true;
+            auto stage = [&](T& pt, T& pr, T& ptheta, T& pphi, T r_stage, T dtheta) {
+                if constexpr (FAST) {
+                    double sn, cs;
+                    if constexpr (kNear) {
+                        within = within && (__builtin_fabs(dtheta) <= near_limit);
+                        sincos_near(aux.sn, aux.cs, dtheta, sn, cs);
+                    } else {
+                        kr_sincos_f64(s.theta + dtheta, sn, cs);
+                    }
+                    momentum_fast_sc(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, sn, cs, a);
+                } else {
+                    eval<T, false>(pt, pr, ptheta, pphi, s, r_stage, s.theta + dtheta, a);
+                }
+            };
+            T pt2, pr2, ptheta2, pphi2;
+            stage(pt2, pr2, ptheta2, pphi2, s.r + (step / 2) * pr1, (step / 2) * ptheta1);
+            acc_t = pt1 + 2 * pt2;
+            acc_phi = pphi1 + 2 * pphi2;
+            T pt3, pr3, ptheta3, pphi3;
+            stage(pt3, pr3, ptheta3, pphi3, s.r + (step / 2) * pr2, (step / 2) * ptheta2);
+            acc_t = acc_t + 2 * pt3;
+            acc_phi = acc_phi + 2 * pphi3;
+            acc_r = pr1 + 2 * pr2 + 2 * pr3;
+            acc_theta = ptheta1 + 2 * ptheta2 + 2 * ptheta3;
+            stage(pt4, pr4, ptheta4, pphi4, s.r + step * pr3, step * ptheta3);
+            return within;
         };
-        T pt2, pr2, ptheta2, pphi2;
-        stage(pt2, pr2, ptheta2, pphi2, s.r + (step / 2) * pr1, (step / 2) * ptheta1);
-        T acc_t = pt1 + 2 * pt2, acc_phi = pphi1 + 2 * pphi2;
-        T pt3, pr3, ptheta3, pphi3;
-        stage(pt3, pr3, ptheta3, pphi3, s.r + (step / 2) * pr2, (step / 2) * ptheta2);
-        acc_t = acc_t + 2 * pt3;
-        acc_phi = acc_phi + 2 * pphi3;
-        T acc_r = pr1 + 2 * pr2 + 2 * pr3, acc_theta = ptheta1 + 2 * ptheta2 + 2 * ptheta3;
-        T pt4, pr4, ptheta4, pphi4;
-        stage(pt4, pr4, ptheta4, pphi4, s.r + step * pr3, step * ptheta3);
+        if constexpr (FAST && KR_STAGE_SINCOS_NEAR) {
+            if (!stages(std::true_type{})) stages(std::false_type{});
+        } else {
+            stages(std::false_type{});
+        }
         // x += (step/6)(k1 + 2k2 + 2k3 + k4), summed left to right as in :908-912
         const T w = FAST ? step * T(1.0 / 6.0) : dv<LeanDefault<T>::value>(step, T(6));
         s.t += w * (acc_t + pt4);
