@@ -298,7 +298,7 @@ KR_DEV void momentum_fast(double& pt, double& pr, double& ptheta, double& pphi, 
                           double* rdotsq_o = nullptr)
 {
     double s, c;
-    kr_sincos_f64(theta, s, c);
+    kr_sincos_fast_f64(theta, s, c);
     momentum_fast_sc(pt, pr, ptheta, pphi, k, h, Q, rdot_sign, thetadot_sign, r, s, c, a, aux, thetadotsq_o, rdotsq_o);
 }
 
@@ -342,7 +342,7 @@ KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
 #pragma clang fp contract(fast)
     const double r = s.r, theta = s.theta, k = s.k, h = s.h;
     double sn, c;
-    kr_sincos_f64(theta, sn, c);   // (carrying sin/cos from step to step by angle addition was measured 6 % SLOWER: register pressure)
+    kr_sincos_fast_f64(theta, sn, c);   // (carrying sin/cos from step to step by angle addition was measured 6 % SLOWER)
     const double s2 = sn * sn;
     const double ac = a * c;
     const double r2 = r * r;
@@ -555,7 +555,7 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
                         within = within && (__builtin_fabs(dtheta) <= near_limit);
                         sincos_near(aux.sn, aux.cs, dtheta, sn, cs);
                     } else {
-                        kr_sincos_f64(s.theta + dtheta, sn, cs);
+                        kr_sincos_fast_f64(s.theta + dtheta, sn, cs);
                     }
                     momentum_fast_sc(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, sn, cs, a);
                 } else {

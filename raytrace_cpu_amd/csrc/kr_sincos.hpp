@@ -63,3 +63,40 @@ KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
     sincos(x, &s, &c);
 #endif
 }
+
+// The same pair for the fast arithmetic path (kr_device.hpp: momentum_fast / k1_with_flips_fast), which tolerates a few
+// ulp per operation: identical two-step Cody-Waite reduction, plain Horner kernels without the tail corrections
+// (sin: r + r z S(z), cos: 1 + z C(z); degree 13 / 14 as above), quadrant fix-up.  <= ~1.5 ulp for |x| < 1024, about 35
+// instructions against ~85 for the <1-ulp routine above.  Arguments outside that range take the routine above.
+KR_SC_FN void kr_sincos_fast_f64(double x, double& s, double& c)
+{
+    if (__builtin_expect(!(__builtin_fabs(x) < 1024.0), 0)) {
+        kr_sincos_f64(x, s, c);
+        return;
+    }
+    const double t = __builtin_rint(x * 6.36619772367581382433e-01);
+    const int n = (int) t;
+    double r = __builtin_fma(-t, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-t, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cr = __builtin_fma(z, pc, 1.0);
+    const bool odd = (n & 1) != 0;
+    const double ss = odd ? cr : sr;
+    const double cc = odd ? sr : cr;
+    const unsigned long long sgn_s = ((unsigned long long) (unsigned) (n & 2)) << 62;
+    const unsigned long long sgn_c = ((unsigned long long) (unsigned) ((n + 1) & 2)) << 62;
+    s = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, ss) ^ sgn_s);
+    c = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, cc) ^ sgn_c);
+}

@@ -12,6 +12,7 @@ int main(int argc, char** argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 2000000;
     const double lo = argc > 2 ? atof(argv[2]) : -1.0, hi = argc > 3 ? atof(argv[3]) : 4.2;
+    const bool fast = argc > 4 && !strcmp(argv[4], "fast");      // the fast-path routine instead of the strict-path one
     double ms = 0, mc = 0, gs = 0, gc = 0;
     long es = 0, ec = 0;
     unsigned long long st = 88172645463325252ull;
@@ -20,7 +21,8 @@ int main(int argc, char** argv)
         double x = lo + (hi - lo) * ((st >> 11) * (1.0 / 9007199254740992.0));
         if (i < 64) x = (i % 8) * 0.78539816339744830962 + (i / 8 - 4) * 1e-9 * ((i & 1) ? 1 : -1);   // around multiples of pi/4
         double s, c;
-        kr_sincos_f64(x, s, c);
+        if (fast) kr_sincos_fast_f64(x, s, c);
+        else kr_sincos_f64(x, s, c);
         const long double ls = sinl((long double) x), lc = cosl((long double) x);
         const double us = (double) (fabsl((long double) s - ls) / ulp_of((double) ls)), uc = (double) (fabsl((long double) c - lc) / ulp_of((double) lc));
         if (us > ms) ms = us;

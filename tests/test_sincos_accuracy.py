@@ -14,3 +14,12 @@ def test_compact_sincos_error_bounds(tmp_path):
         assert ms < 1.0 and mc < 1.0, (args, ms, mc)          # vs long double
         assert gs <= 1.0 and gcs <= 1.0, (args, gs, gcs)      # vs glibc double
         assert es > 0.95 and ec > 0.95                         # and bit-equal to glibc for > 95 % of arguments
+
+
+def test_fast_path_sincos_error_bounds(tmp_path):
+    """kr_sincos_fast_f64 (fast arithmetic path only): no tail corrections, a few-ulp contract -- held to 2 ulp."""
+    exe = str(tmp_path / "sincos_check")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(gc.ROOT, "tests", "sincos_check.cpp"), "-lm"])
+    for args in (["2000000", "-1.0", "4.2"], ["1000000", "-40", "40"], ["500000", "1.5707", "1.5709"], ["500000", "-1e-3", "1e-3"]):
+        n, ms, mc, gs, gcs, es, ec = (float(x) for x in subprocess.check_output([exe] + args + ["fast"], text=True).split())
+        assert ms <= 2.0 and mc <= 2.0, (args, ms, mc)
