@@ -238,6 +238,7 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
 KR_DEV double fast_rcp(double x)
 {
     double y = __builtin_amdgcn_rcp(x);
+
     y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
     y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
     return y;

@@ -426,6 +426,13 @@ __global__ void __launch_bounds__(kBlock) arith_probe_kernel(int op, const doubl
             case 8: ::sincos(x, &s, &c); r = s; break;      // device libm
             case 9: ::sincos(x, &s, &c); r = c; break;
             case 10: r = ::pow(x, y); break;
+            case 11: { double v = __builtin_amdgcn_rcp(y); r = x * v; } break;                                             // raw v_rcp_f64
+            case 12: { double v = __builtin_amdgcn_rcp(y); v = __builtin_fma(__builtin_fma(-y, v, 1.0), v, v); r = x * v; } break;   // + one Newton step
+            case 13: { double v = __builtin_amdgcn_rsq(x); r = x * v; } break;                                             // raw v_rsq_f64
+            case 14: { double v = __builtin_amdgcn_rsq(x); double g = x * v, h = 0.5 * v; const double e = __builtin_fma(-h, g, 0.5);
+                       r = __builtin_fma(g, e, g); } break;                                                                  // + one coupled step
+            case 15: kr_sincos_fast_f64(x, s, c); r = s; break;
+            case 16: kr_sincos_fast_f64(x, s, c); r = c; break;
         }
         out[i] = r;
     }
