@@ -182,9 +182,10 @@ def test_range_phi_bitwise(krlib):
 
 
 # ---- edge cases ------------------------------------------------------------------------------------------------
-def test_empty_and_skipped_inputs(krlib):
+@pytest.mark.parametrize("flags", MODES)
+def test_empty_and_skipped_inputs(krlib, flags):
     p = capi.default_params(gc.SPIN)
-    p.integrator = capi.RK4
+    p.integrator, p.flags = capi.RK4, flags
     empty = np.zeros(0, dtype=capi.RAY_F64)
     out, st = api.trace(p, empty)
     assert len(out) == 0 and st["rays_traced"] == 0
@@ -198,11 +199,12 @@ def test_empty_and_skipped_inputs(krlib):
     assert ol.rays_equal_bitwise(out, rays) == []
 
 
-def test_ragged_sizes_match_oracle(krlib):
+@pytest.mark.parametrize("flags", [pytest.param(0, id="strict"), pytest.param(capi.FLAG_HYBRID, id="hybrid")])
+def test_ragged_sizes_match_oracle(krlib, flags):
     """n not a multiple of the wave / workgroup size, down to a single ray."""
     g = np.load(gc.golden_path("ps_h10"))
     init = g["init"]
-    p = CASES["ps_h10"]["runs"]["rk4"]
+    p = capi.copy_params(CASES["ps_h10"]["runs"]["rk4"], flags=flags)
     for n in (1, 63, 64, 65, 257, 1001):
         sub = init[200:200 + n].copy()
         out, _ = api.trace(p, sub)
