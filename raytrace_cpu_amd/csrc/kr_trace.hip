@@ -10,7 +10,11 @@
 //     back and, through one wave-aggregated atomicAdd on a global queue head (ballot + popcount), pulls the
 //     next unprocessed ray, so a wave never idles on its slowest ray while work is left.  One loop iteration =
 //     one integration step (RK45: one trial step) for every lane that holds a ray;
-//   * the grid is sized to the device (CUs x resident waves), not to n.
+//   * the grid is sized to the device (CUs x resident waves), not to n;
+//   * a launch cannot end before its longest ray does.  Large launches are therefore split in two concurrent ones
+//     (dispatch_split): the few ill-conditioned rays -- in the lamp-post workloads also the longest -- run the strict
+//     arithmetic on waves that own their SIMDs (HOG instances), everything else fills the rest of the chip, with the
+//     fast arithmetic (KR_FLAG_HYBRID) or the strict one (flags = 0; same bits as a single launch).
 //
 // Work-queue exit: every wave leaves the loop once the queue head has passed n AND none of its lanes holds a
 // ray; every ray ends after at most steplim iterations (steps is incremented on every path through a step,
@@ -32,9 +36,6 @@ namespace kr {
 namespace {
 
 constexpr int kBlock = 256;          // 4 independent waves per workgroup, no barriers
-#ifndef KR_MIN_WAVES
-#define KR_MIN_WAVES 1               // __launch_bounds__ 2nd argument: minimum waves per SIMD the register allocator must allow
-#endif
 #ifndef KR_REFILL_MIN
 #define KR_REFILL_MIN 1
 #endif
