@@ -94,3 +94,71 @@ def test_row_cyclic_shards_reduce_to_the_global_histogram():
     key = lambda a: np.lexsort((a[:, 1], a[:, 0]))
     np.testing.assert_allclose(union[key(union)], glob[key(glob)], rtol=0, atol=1e-12)
     assert int(res[0][2][1]) == st_full["steps_total"]
+
+
+# ---- image plane: ray-cyclic shards, all-reduce of the seven planes (bench.py --workload imageplane) ---------------
+IMG = 8
+
+
+def _image_planes(rays):
+    o = ol.oracle()
+    spin = bench.SPIN
+    p = capi.default_params(-spin)
+    p.integrator, p.r_max = capi.RK4, 11000.0
+    out, st = ol.oracle_trace(p, rays, nthreads=2)
+    o.kro_redshift_f64(-spin, -1.0, 1, 0, 0, ol.ptr(out), len(out))
+    o.kro_range_phi_f64(-np.pi, np.pi, ol.ptr(out), len(out))
+    b = capi.ImageBins()
+    b.x0, b.y0, b.img_dx, b.img_dy = -30.0, -30.0, 60.0 / IMG, 60.0 / IMG
+    b.r_isco, b.r_disc = o.kro_kerr_isco(spin, 1), 30.0
+    b.q1, b.rb1, b.q2, b.rb2, b.q3 = 3.0, 4.0, 3.0, 10.0, 3.0
+    b.img_nx, b.img_ny, b.flip_image, b.pad = IMG, IMG, 1, 0
+    npix = IMG * IMG
+    n = np.zeros(npix, dtype=np.int32)
+    planes = [np.zeros(npix) for _ in range(6)]
+    dc = C.c_int64()
+    o.kro_reduce_image_f64(C.byref(b), ol.ptr(out), len(out), ol.ptr(n), *[ol.ptr(x) for x in planes], C.byref(dc))
+    return np.concatenate([n.astype(np.float64)] + planes + [[float(dc.value)]]), st
+
+
+def _image_init():
+    spec = ol.imageplane_spec(10000.0, 80.0, -30.0, 30.0, 60.0 / 23, -30.0, 30.0, 60.0 / 23, bench.SPIN)
+    rays = ol.oracle_imageplane(spec)
+    ol.oracle().kro_redshift_start_f64(-bench.SPIN, 0.0, 1, 0, ol.ptr(rays), len(rays))
+    return rays
+
+
+def _image_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = _image_init()[rank::world].copy()      # what kr_imageplane_init_strided_dev_f64(spec, first = rank, stride = world) generates
+    h, st = _image_planes(mine)
+    t = torch.from_numpy(h.copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    q.put((rank, t.numpy().copy(), st["rays_traced"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ray_cyclic_image_shards_reduce_to_the_global_planes():
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_image_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full, st_full = _image_planes(_image_init())
+    npix = IMG * IMG
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][1][:npix], full[:npix])          # per-pixel ray counts: exact
+    assert res[0][1][-1] == full[-1] > 0                                   # disc rays
+    np.testing.assert_allclose(res[0][1], full, rtol=1e-12)
+    assert res[0][2] + res[1][2] == st_full["rays_traced"]
