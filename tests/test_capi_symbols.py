@@ -99,3 +99,13 @@ def test_device_resident_programs_fail_loudly_without_gpu(app, par, tmp_path):
     r = subprocess.run([exe, f"--parfile={os.path.join(ROOT, 'tests', 'golden', 'apps', par)}", f"--outfile={out}"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and not out.exists()
     assert "no HIP device available" in r.stderr or "no ROCm-capable device" in r.stderr
+
+
+def test_bench_refuses_to_run_without_gpu():
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout) and not [l for l in r.stdout.splitlines() if l.startswith("{")]
