@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -182,6 +183,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
         if (!any_have) break;   // nothing held and (exhausted or nothing needed): only reachable when exhausted
 
 #if KR_LONG_RAY_PRIO
+        if constexpr (!HOG)                    // (a wave that owns its SIMD has nobody to take priority over)
         // The launch cannot end before its longest ray does, and a ray advances one step per iteration of ITS wave:
         // a wave that carries a long ray (orbiting / polar-axis rays: 2e4..1e7 steps against a median of ~450) is
         // given issue priority over its SIMD neighbours so that the critical path runs at single-wave speed
@@ -329,6 +331,16 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
     c.sp0 = (T) p->stop_params[0]; c.sp1 = (T) p->stop_params[1]; c.sp2 = (T) p->stop_params[2];
     c.inv_precision = (T) (1.0 / p->precision);
     c.inv_theta_precision = (T) (1.0 / p->theta_precision);
+    {
+        // div_by_uniform (kr_device.hpp) needs a finite, normal divisor with a normal reciprocal and a significand that is not all ones
+        auto qualifies = [](double b) {
+            if (!(std::fabs(b) >= 1e-300 && std::fabs(b) <= 1e300)) return false;
+            int e;
+            const double m = std::frexp(std::fabs(b), &e);          // m in [0.5, 1)
+            return m != 1.0 - std::ldexp(1.0, -53);
+        };
+        c.inv_ok = qualifies(p->precision) && qualifies(p->theta_precision);
+    }
     c.steplim = steplim;
     c.stop_kind = p->stop_kind;
     return c;

@@ -104,3 +104,15 @@ def test_device_libm_distance_from_glibc(krlib):
     assert ulps(probe(8, x), np.sin(x)).max() <= 2 and ulps(probe(9, x), np.cos(x)).max() <= 2
     base = rng.uniform(1e-3, 1e10, 500_000)
     assert ulps(probe(10, base, np.full_like(base, 0.2)), base ** 0.2).max() <= 2
+
+
+def test_division_by_a_uniform_constant_is_correctly_rounded(krlib):
+    """kr_device.hpp::div_by_uniform (step / precision, / theta_precision, / 6 on the strict path): 3 instructions with a host-side
+    correctly rounded reciprocal, bit-identical to IEEE division for every numerator."""
+    rng = np.random.default_rng(11)
+    a, _ = operands(rng, 1_000_000)
+    a = np.concatenate([a, np.abs(a) * 1e-3, rng.uniform(0, 10, 200_000), [0.0, 1.0, 100.0, 1e-3, 5e-324, 1e300]])
+    for b in (100.0, 50.0, 6.0, 3.0, 7.0, 10.0, 1e-5, 123456.789, 0.1, 1.9999999999999996 / 3):
+        got = probe(17, a, np.full_like(a, b))
+        want = a / b
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), b
