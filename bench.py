@@ -284,7 +284,7 @@ class ReturnRadiationWorkload:
             if tot is None:
                 tot = dict(st)
             else:
-                for k in ("rays_traced", "steps_total", "rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "kernel_ms"):
+                for k in ("rays_traced", "steps_total", "rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "rk45_extrapolated_steps", "kernel_ms"):
                     tot[k] += st[k]
         return tot
 
@@ -434,7 +434,7 @@ def main():
         if others:
             out["other_arithmetic_modes"] = others
         if args.integrator == "rk45":
-            out["rk45"] = {k: int(stats_last[k]) for k in ("rk45_attempts", "rk45_rejects", "rk45_stationary_steps")}
+            out["rk45"] = {k: int(stats_last[k]) for k in ("rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "rk45_extrapolated_steps")}
         if world > 1:
             pass                                    # cpu_baseline is an N = 1 leg only
         elif not args.no_cpu_baseline and args.workload == "emissivity":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 4
+#define KR_ABI_VERSION 5
 
 /* error codes */
 #define KR_OK          0
@@ -77,6 +77,8 @@ extern "C" {
                                            The call synchronises `stream` once (an 8-byte read-back sizes the side launch) and
                                            uses a second, internal stream of its own priority level for the concurrent launch.
                                            Ignored by the f32 entry points and when KR_FLAG_FAST_MATH is set. */
+#define KR_FLAG_RK45_ITERATE_ALL (1 << 2) /* RK45: iterate creeping captured rays to the step limit one step at a time, as the reference does,
+                                           instead of extrapolating them (kr_stats.rk45_extrapolated_steps) */
 #define KR_FLAG_BLOCKS_PER_CU(n)      (((n) & 0xF) << 8)   /* resident 256-thread workgroups per CU for the trace kernel, 0 = default (2) */
 #define KR_FLAG_GET_BLOCKS_PER_CU(f)  (((f) >> 8) & 0xF)
 
@@ -142,6 +144,9 @@ typedef struct kr_stats {
     int64_t rk45_stationary_steps;  /* RK45: steps (included in steps_total and rk45_attempts) that were replayed as bare t/phi
                                        additions after a captured ray reached an exact fp64 fixed point in (r, theta, step);
                                        bit-identical to iterating them (kr_device.hpp::step_rk45) */
+    int64_t rk45_extrapolated_steps; /* RK45: steps (included in steps_total and rk45_attempts) of captured rays whose r was stationary
+                                       and whose theta advanced by a constant number of ulps per step: extrapolated to the step
+                                       limit (r, theta, every integer output exact; t, phi, momenta to ~1e-11) */
 } kr_stats;
 
 /* PointSource<T> ctor arguments (pointsource.h:24, pointsource.cpp:11-64) */

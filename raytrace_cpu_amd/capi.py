@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -19,6 +19,7 @@ STATUS_ERGO, STATUS_NEG_ENERGY, STATUS_NAN = 16, 32, 64
 STEPLIM, RK45_STEPLIM, MIN_STEP = 10_000_000, 100_000, 1e-3
 FLAG_FAST_MATH = 1
 FLAG_HYBRID = 2
+FLAG_RK45_ITERATE_ALL = 4
 
 # Ray<double> / Ray<float>  (reference src/raytracer/raytracer.h:65-78)
 _F64 = [(n, "<f8") for n in ("t", "r", "theta", "phi", "pt", "pr", "ptheta", "pphi", "k", "h", "Q", "emit", "redshift")]
@@ -37,7 +38,7 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("rays_total", "rays_traced", "steps_total", "rk45_attempts", "rk45_rejects")] + \
-               [(n, C.c_double) for n in ("kernel_ms", "h2d_ms", "d2h_ms")] + [("rays_strict_side", C.c_int64), ("rk45_stationary_steps", C.c_int64)]
+               [(n, C.c_double) for n in ("kernel_ms", "h2d_ms", "d2h_ms")] + [("rays_strict_side", C.c_int64), ("rk45_stationary_steps", C.c_int64), ("rk45_extrapolated_steps", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

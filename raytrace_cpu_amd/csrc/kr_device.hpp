@@ -137,6 +137,7 @@ template <typename T> struct TraceConsts {
     T sp0, sp1, sp2;        // stop_params
     T inv_precision, inv_theta_precision;   // RN(1/precision), RN(1/theta_precision): fast path, and div_by_uniform on the strict one
     bool inv_ok;                            // both divisors qualify for div_by_uniform
+    bool rk45_extrapolate;                  // RK45: creeping captured rays are extrapolated to the step limit (default)
     int32_t steplim;
     int32_t stop_kind;
 };
@@ -156,6 +157,10 @@ template <typename T> struct Lane {
     T theta_eq_prev;
     T theta_prev;
     bool in_retry;          // a trial step was rejected: next iteration retries with the same k1
+    int32_t creep_m;        // theta advanced by exactly this many ulps in the last creeping outer step (0: none) ...
+    int32_t creep_run;      // ... and in this many consecutive outer steps before it
+    bool creep_mode;        // the rest of the ray is replayed step by step from k1 alone (step_rk45)
+    T creep_dt, creep_dphi; // its t and phi increments per step
 };
 
 // momentum_from_consts, src/include/kerr.h:300-335
@@ -621,6 +626,10 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     return !loop_cond<T, USE_DEST>(s, c);
 }
 
+#ifndef KR_CREEP_RUN
+#define KR_CREEP_RUN 8      // consecutive creeping outer steps (same ulp count) before the rest of a captured ray is extrapolated
+#endif
+
 // ---- RK45 / DOPRI5 (raytracer.cpp:1260-1598, :1600-1894) ----------------------------------------
 template <typename T> struct Dopri {
     // Butcher tableau, :1316-1330, formed exactly as T(n)/d
@@ -662,15 +671,79 @@ KR_DEV void rk45_seed(Lane<T>& s, const TraceConsts<T>& c)
     s.in_retry = false;
 }
 
+// One outer step of a lane in creep mode (see the end of step_rk45): what the full step would do at its start -- ++steps, k1
+// with the turning-point tests, the ERGO / NEG_ENERGY flags, all on the real code path -- then the increments that are known:
+// r stays, theta moves by creep_m ulps (integer arithmetic on its bits), t and phi by their recorded increments (these two,
+// and the momenta left in the record, are accurate to ~1e-11 rather than to the bit).  If k1 does anything but confirm the
+// state (a sign flip, a turning-point flag), everything is put back and the lane returns to full steps.  When both status
+// bits can no longer change, the remaining steps are applied at once.  Returns 1: ray finished, 0: continue, -1: left creep mode.
+template <typename T, bool USE_DEST, bool FAST>
+KR_DEV int creep_step(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& creep_steps)
+{
+    const T a = c.a;
+    const Lane<T> keep = s;
+    ++s.steps;
+    bool confirmed;
+    if constexpr (FAST) {
+        FastAux aux;
+        confirmed = !k1_with_flips_fast(s, a, aux);
+        if (confirmed) {
+            if (s.pt <= 0) s.status |= KR_STATUS_ERGO;
+            const T two_r_rho = 2 * s.r * aux.inv_rhosq;
+            if ((1 - two_r_rho) * s.pt + (two_r_rho * a * aux.sin2theta) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
+        }
+    } else {
+        T rhosq, sin2theta;
+        confirmed = !k1_with_flips<T, true>(s, a, rhosq, sin2theta);
+        if (confirmed) {
+            if (s.pt <= 0) s.status |= KR_STATUS_ERGO;
+            if ((1 - 2 * s.r / rhosq) * s.pt + (2 * a * s.r * sin2theta / rhosq) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
+        }
+    }
+    if (!confirmed || s.rdot_sign != keep.rdot_sign || s.thetadot_sign != keep.thetadot_sign || s.rdot_flips != keep.rdot_flips ||
+        s.r_was_positive != keep.r_was_positive || s.theta_was_positive != keep.theta_was_positive) {
+        s = keep;
+        s.creep_mode = false;
+        s.creep_run = 0;
+        s.creep_m = 0;
+        return -1;
+    }
+    long long todo = 1;
+    if ((s.status & KR_STATUS_NEG_ENERGY) && ((s.status & KR_STATUS_ERGO) || s.pt > T(1))) {
+        todo = 1 + ((long long) c.steplim - s.steps);        // neither flag can change any more: this step and all the remaining ones
+        s.steps = c.steplim;
+    }
+    const long long bits = (long long) __builtin_bit_cast(unsigned long long, (double) s.theta) + (long long) s.creep_m * todo;
+    s.theta = (T) __builtin_bit_cast(double, (unsigned long long) bits);
+    s.t = s.t + (T) todo * s.creep_dt;
+    s.phi = s.phi + (T) todo * s.creep_dphi;
+    attempts += (uint32_t) todo;
+    creep_steps += (uint32_t) todo;
+    return (s.steps < c.steplim) ? 0 : 1;
+}
+
 // One wave iteration of RK45 = at most one TRIAL step per lane.  The reference nests a retry loop inside
 // the outer step (:1438-1541); here a rejected lane keeps its k1 (s.pt..s.pphi hold k1 until a trial is
 // accepted) and retries on the next iteration, so a rejection never stalls the other 63 lanes.
 // attempts/rejects are per-lane counters.  Returns true when the ray has finished.
 template <typename T, bool USE_DEST, bool FAST>
-KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& rejects, uint32_t& stationary_steps)
+KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& rejects, uint32_t& stationary_steps, uint32_t& creep_steps,
+                      int replay_batch)
 {
     using D = Dopri<T>;
     const T a = c.a;
+
+    if constexpr (sizeof(T) == 8) {
+        if (s.creep_mode) {
+            // replay_batch > 1 when every ray of the wave is in creep mode (the tail of a launch): several outer steps per wave iteration
+            for (int u = 0; u < replay_batch; ++u) {
+                const int rc = creep_step<T, USE_DEST, FAST>(s, c, attempts, creep_steps);
+                if (rc > 0) return true;
+                if (rc < 0) break;                 // back to full steps, starting with this one
+                if (u + 1 == replay_batch) return false;
+            }
+        }
+    }
 
     // snapshot of every variable that feeds back into the next outer step (for the fixed-point test below)
     const bool fresh = !s.in_retry;
@@ -767,8 +840,10 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     sum_phi = sum_phi + D::b6 * pphi_i;
 
     // 5th-order solution (:1493-1499); the polar reflection mutates thetadot_sign even if the trial is rejected
-    T r_new = r + h_try * (D::b1 * pr1 + D::b3 * pr3 + D::b4 * pr4 + D::b5 * pr5 + D::b6 * pr6);
-    T theta_new = theta + h_try * (D::b1 * ptheta1 + D::b3 * ptheta3 + D::b4 * ptheta4 + D::b5 * ptheta5 + D::b6 * ptheta6);
+    const T inc_r = h_try * (D::b1 * pr1 + D::b3 * pr3 + D::b4 * pr4 + D::b5 * pr5 + D::b6 * pr6);
+    const T inc_theta = h_try * (D::b1 * ptheta1 + D::b3 * ptheta3 + D::b4 * ptheta4 + D::b5 * ptheta5 + D::b6 * ptheta6);
+    T r_new = r + inc_r;
+    T theta_new = theta + inc_theta;
     T t_new = s.t + h_try * sum_t;
     T phi_new = s.phi + h_try * sum_phi;
     const bool inside_poles = !(theta_new < T(0)) && !(theta_new > T(kPi));
@@ -835,6 +910,49 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
         if (!(err_norm <= T(1))) rejects += (uint32_t) remaining;
         stationary_steps += (uint32_t) remaining;
         return true;
+    }
+
+    // Creep.  Most captured rays do not reach that fixed point: r is stationary (its increment is a fraction of an ulp) but
+    // the theta increment h Sum(b_i thetadot_i) stays near a whole number m >= 1 of ulps, so theta advances by exactly m ulps
+    // per outer step, for ever -- 100 000 steps of seven evaluations each for a ray no application uses (its step count is
+    // stored negative).  Over the ~1e5 ulps still to go theta changes by 1e-11 of itself, and so does every quantity of the
+    // step.  Once the step has been of this kind KR_CREEP_RUN times in a row, with margins that 1e-11 cannot consume (trial
+    // accepted at half the tolerance; increments at least 1e-6 ulp away from the rounding boundaries at 1/2 ulp and
+    // m +- 1/2 ulps; no equator / pole / stop angle / binade boundary inside the range theta will cover), the lane switches to
+    // creep mode (creep_step below): each further outer step evaluates only what can still change the ray's integer outputs
+    // -- k1 with its turning-point tests and the two status flags -- and applies the known increments.
+    if constexpr (sizeof(T) == 8) {
+        bool creeping = false;
+        if (c.rk45_extrapolate && fresh && inside_poles && s.r == r && s.rdot_sign == rs_in && s.thetadot_sign == ts_in && s.r_was_positive == rwp_in &&
+            s.theta_was_positive == twp_in && !(s.r <= c.horizon) && err_norm <= T(0.5) && !clamped &&
+            (!USE_DEST || c.stop_kind != KR_STOP_FLATPLANE) && theta > T(0)) {
+            const long long b0 = (long long) __builtin_bit_cast(unsigned long long, (double) theta);
+            const long long b1 = (long long) __builtin_bit_cast(unsigned long long, (double) s.theta);
+            const long long m = b1 - b0;
+            const double ulp_th = __builtin_bit_cast(double, (unsigned long long) b0 & 0x7FF0000000000000ull) * 2.220446049250313e-16;
+            const double ulp_r = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, (double) r) & 0x7FF0000000000000ull) * 2.220446049250313e-16;
+            const long long am = m < 0 ? -m : m;
+            if (am >= 1 && am <= 65536 && ((b0 ^ b1) >> 52) == 0 && __builtin_fabs((double) inc_theta - (double) m * ulp_th) <= 0.499999 * ulp_th &&
+                __builtin_fabs((double) inc_r) <= 0.499999 * ulp_r) {
+                creeping = true;
+                s.creep_run = ((int32_t) m == s.creep_m) ? s.creep_run + 1 : 1;
+                s.creep_m = (int32_t) m;
+                const long long remaining = (long long) c.steplim - s.steps;
+                if (s.creep_run >= KR_CREEP_RUN && remaining > 0) {
+                    const long long b_end = b1 + m * remaining;
+                    const double th_end = __builtin_bit_cast(double, (unsigned long long) b_end);
+                    const double lo = __builtin_fmin((double) s.theta, th_end), hi = __builtin_fmax((double) s.theta, th_end);
+                    auto outside = [&](double x) { return !(x >= lo && x <= hi); };      // x is not a value theta will take
+                    if (((b1 ^ b_end) >> 52) == 0 && lo > 0.0 && hi < kPi && outside(kPi2) && outside(__builtin_fabs((double) c.thetalim)) &&
+                        outside(__builtin_fabs((double) c.sp0)) && outside(__builtin_fabs((double) c.sp2))) {
+                        s.creep_mode = true;
+                        s.creep_dt = h_try * sum_t;
+                        s.creep_dphi = h_try * sum_phi;
+                    }
+                }
+            }
+        }
+        if (!creeping) { s.creep_run = 0; s.creep_m = 0; }
     }
 
     if (crossed_equator(s.theta_eq_prev, s.theta)) ++s.eq_cross;   // once per accepted outer step (:1542-1544)

@@ -49,7 +49,7 @@ constexpr int kBlock = 256;          // 4 independent waves per workgroup, no ba
 #ifndef KR_LONG_RAY_STEPS
 #define KR_LONG_RAY_STEPS 2048
 #endif
-constexpr int kCounters = 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps
+constexpr int kCounters = 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps, [6] rk45 extrapolated steps
 
 template <typename T> struct RayOf;
 template <> struct RayOf<double> { using type = kr_ray_f64; };
@@ -136,7 +136,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     bool have = false;          // this lane holds a ray
     bool exhausted = false;     // wave-uniform: the queue head has passed n
     unsigned long long my_steps = 0, my_traced = 0;
-    uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0;
+    uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
 #if KR_LONG_RAY_PRIO
     int has_prio = 0;
 #endif
@@ -167,6 +167,9 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
                         s.r_was_positive = false;
                         s.theta_was_positive = true;
                         s.in_retry = false;
+                        s.creep_m = 0;
+                        s.creep_run = 0;
+                        s.creep_mode = false;
                         if (METHOD == KR_RK45) rk45_seed(s, c);
                         if (!loop_cond<T, USE_DEST>(s, c)) {
                             // zero-iteration call: only the epilogue runs
@@ -209,11 +212,16 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
         }
 #endif
 
+        int replay_batch = 1;
+        if constexpr (METHOD == KR_RK45 && sizeof(T) == 8) {
+            // the tail of an RK45 launch is waves that hold nothing but creeping captured rays: they take 16 cheap steps per iteration
+            if (!__any(have && !s.creep_mode)) replay_batch = 16;
+        }
         if (have) {
             bool fin;
             if (METHOD == KR_EULER) fin = step_fixed<T, false, USE_DEST, FAST>(s, c);
             else if (METHOD == KR_RK4) fin = step_fixed<T, true, USE_DEST, FAST>(s, c);
-            else fin = step_rk45<T, USE_DEST, FAST>(s, c, my_attempts, my_rejects, my_stationary);
+            else fin = step_rk45<T, USE_DEST, FAST>(s, c, my_attempts, my_rejects, my_stationary, my_creep, replay_batch);
             if (fin) {
                 my_steps += (unsigned long long) s.steps;
                 const int32_t out_steps = finish_status<T, USE_DEST>(s, c);
@@ -229,8 +237,10 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     const unsigned long long w_att = wave_sum<T>((unsigned long long) my_attempts);
     const unsigned long long w_rej = wave_sum<T>((unsigned long long) my_rejects);
     const unsigned long long w_sta = wave_sum<T>((unsigned long long) my_stationary);
+    const unsigned long long w_creep = wave_sum<T>((unsigned long long) my_creep);
     if (lane == 0) {
         if (w_sta) atomicAdd(&counters[5], w_sta);
+        if (w_creep) atomicAdd(&counters[6], w_creep);
         if (w_traced) atomicAdd(&counters[1], w_traced);
         if (w_steps) atomicAdd(&counters[2], w_steps);
         if (w_att) atomicAdd(&counters[3], w_att);
@@ -331,6 +341,7 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
     c.sp0 = (T) p->stop_params[0]; c.sp1 = (T) p->stop_params[1]; c.sp2 = (T) p->stop_params[2];
     c.inv_precision = (T) (1.0 / p->precision);
     c.inv_theta_precision = (T) (1.0 / p->theta_precision);
+    c.rk45_extrapolate = !(p->flags & KR_FLAG_RK45_ITERATE_ALL);
     {
         // div_by_uniform (kr_device.hpp) needs a finite, normal divisor with a normal reciprocal and a significand that is not all ones
         auto qualifies = [](double b) {
@@ -540,6 +551,7 @@ int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, k
         stats->rk45_attempts = (int64_t) h[3];
         stats->rk45_rejects = (int64_t) h[4];
         stats->rk45_stationary_steps = (int64_t) h[5];
+        stats->rk45_extrapolated_steps = (int64_t) h[6];
         stats->kernel_ms = ms;
     }
     return KR_OK;

@@ -49,6 +49,6 @@ for h in (5.0, 10.0):
         ok = (h4["count"] >= 100) & (hh["count"] >= 100)
         dev = np.abs(hh["emis"][ok] / h4["emis"][ok] - 1)
         out["runs"].append({"h": h, "integrator": "rk45", "tol": tol, "rays": st["rays_traced"], "steps": st["steps_total"], "attempts": st["rk45_attempts"], "rejects": st["rk45_rejects"],
-                            "stationary_steps": st["rk45_stationary_steps"], "kernel_ms": st["kernel_ms"], "steps_per_sec": st["steps_total"] / st["kernel_ms"] * 1e3,
+                            "stationary_steps": st["rk45_stationary_steps"], "extrapolated_steps": st["rk45_extrapolated_steps"], "kernel_ms": st["kernel_ms"], "steps_per_sec": st["steps_total"] / st["kernel_ms"] * 1e3,
                             "attempts_per_sec": st["rk45_attempts"] / st["kernel_ms"] * 1e3, "emis_dev_vs_rk4_rms": float(np.sqrt(np.mean(dev ** 2))), "emis_dev_vs_rk4_max": float(dev.max())})
 print(json.dumps(out, indent=1))

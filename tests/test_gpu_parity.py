@@ -417,3 +417,28 @@ def test_strict_launch_split_is_bitwise_neutral(krlib, monkeypatch):
     single, st_single = api.trace(p, init)
     assert st_split["rays_strict_side"] > 0 and st_single["rays_strict_side"] == 0
     assert st_split["steps_total"] == st_single["steps_total"] and _same_bits(split, single)
+
+
+def test_rk45_creep_mode_reproduces_iteration(krlib):
+    """Captured RK45 rays whose theta advances by a whole number of ulps per outer step while r stands still are carried to the
+    step limit from k1 alone (kr_device.hpp::creep_step).  Against iterating every step (KR_FLAG_RK45_ITERATE_ALL), on the strict
+    path: every other ray bit-identical; on the creeping rays r, theta and every integer output bit-identical, t and phi to 1e-10."""
+    g = np.load(gc.golden_path("ps_h5"))
+    p = capi.copy_params(CASES["ps_h5"]["runs"]["rk45"], flags=0)
+    fast_way, st = api.trace(p, g["init"])
+    slow_way, st0 = api.trace(capi.copy_params(p, flags=capi.FLAG_RK45_ITERATE_ALL), g["init"])
+    assert st0["rk45_extrapolated_steps"] == 0 and st["rk45_extrapolated_steps"] > 50 * 90000      # ps_h5: 62 creeping rays
+    assert st["steps_total"] == st0["steps_total"] and st["rk45_attempts"] == st0["rk45_attempts"]
+    approx = ("t", "phi", "pt", "pr", "ptheta", "pphi")
+    moved = np.zeros(len(fast_way), dtype=bool)
+    for f in fast_way.dtype.names:
+        a, b = fast_way[f], slow_way[f]
+        same = (a == b) | (np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64)))
+        if f in approx:
+            moved |= ~same
+        else:
+            assert same.all(), f
+    lim = (slow_way["status"] & capi.STATUS_STEPLIM) != 0
+    assert moved.sum() > 0 and not (moved & ~lim).any()                       # only step-limit rays were touched
+    for f in ("t", "phi"):
+        np.testing.assert_allclose(fast_way[f][moved], slow_way[f][moved], rtol=1e-10)
