@@ -305,8 +305,9 @@ def main():
     ap.add_argument("--radii", type=int, default=100, help="return_radiation: number of source radii")
     ap.add_argument("--rays", type=float, default=0, help="rays per GPU (default: 1e7 emissivity = BASELINE configs[1]; 4097^2 imageplane = configs[3])")
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
-    ap.add_argument("--arithmetic", default="hybrid", choices=["hybrid", "strict", "fast"],
-                    help="hybrid (KR_FLAG_HYBRID: strict for ill-conditioned rays, fast for the rest), strict (flags = 0), fast (KR_FLAG_FAST_MATH)")
+    ap.add_argument("--arithmetic", default="auto", choices=["auto", "hybrid", "strict", "fast"],
+                    help="hybrid (KR_FLAG_HYBRID: strict for ill-conditioned rays, fast for the rest), strict (flags = 0), fast (KR_FLAG_FAST_MATH); "
+                         "auto = hybrid for euler / rk4, strict for rk45 (what the host mirror of the class API does)")
     ap.add_argument("--fast-math", action="store_true", help="same as --arithmetic fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-math-extra", action="store_true")
@@ -339,6 +340,8 @@ def main():
     wl = {"emissivity": EmissivityWorkload, "imageplane": ImagePlaneWorkload, "return_radiation": ReturnRadiationWorkload}[args.workload](args, lib, capi, api, rank, world)
     if args.fast_math:
         args.arithmetic = "fast"
+    if args.arithmetic == "auto":
+        args.arithmetic = "strict" if args.integrator == "rk45" else "hybrid"
     mode_flags = {"strict": 0, "hybrid": capi.FLAG_HYBRID, "fast": capi.FLAG_FAST_MATH}
     mode_mask = capi.FLAG_HYBRID | capi.FLAG_FAST_MATH
     wl.p.flags = (wl.p.flags & ~mode_mask) | mode_flags[args.arithmetic]

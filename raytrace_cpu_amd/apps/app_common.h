@@ -17,10 +17,12 @@ inline void check(int rc, const char* what)
     if (rc != KR_OK) throw std::runtime_error(std::string(what) + ": " + kr_last_error());
 }
 
-// KRTRACE_ARITHMETIC = hybrid (default) | strict | fast, as in the host mirror of the class API
-inline int arithmetic_flags(const std::string& choice)
+// KRTRACE_ARITHMETIC = hybrid | strict | fast, as in the host mirror of the class API; unset: hybrid for the
+// fixed-step integrators, strict for RK45
+inline int arithmetic_flags(const std::string& choice, int integrator)
 {
-    if (choice.empty() || choice == "hybrid") return KR_FLAG_HYBRID;
+    if (choice.empty()) return integrator == KR_RK45 ? 0 : KR_FLAG_HYBRID;
+    if (choice == "hybrid") return KR_FLAG_HYBRID;
     if (choice == "strict") return 0;
     if (choice == "fast") return KR_FLAG_FAST_MATH;
     throw std::invalid_argument("arithmetic: expected hybrid, strict or fast, got '" + choice + "'");

@@ -87,7 +87,7 @@ try {
     p.theta_max = M_PI_2;
     p.r_max = 1.1 * dist;
     p.stop_kind = KR_STOP_THETA;
-    p.flags = krapp::arithmetic_flags(arith);
+    p.flags = krapp::arithmetic_flags(arith, p.integrator);
 
     // ---- device pipeline ------------------------------------------------------------------------------------------
     krapp::check(kr_set_device(args.get_parameter<int>("--device", 0)), "kr_set_device");

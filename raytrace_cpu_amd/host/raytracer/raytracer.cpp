@@ -80,11 +80,14 @@ Raytracer<T>::~Raytracer()
 }
 
 // Arithmetic of the double-precision trace (include/kr_trace.h), chosen by the environment so that
-// the reference's applications need no new option: KRTRACE_ARITHMETIC = hybrid (default) | strict | fast.
-static int arithmetic_flags()
+// the reference's applications need no new option: KRTRACE_ARITHMETIC = hybrid | strict | fast.  Unset: hybrid for the
+// fixed-step integrators, strict for RK45 -- the adaptive step control amplifies the few-ulp differences of the fast
+// arithmetic into +-1 differences of the step counts, and an RK45 launch is bounded by its longest ray either way.
+static int arithmetic_flags(int integrator)
 {
     const char* e = std::getenv("KRTRACE_ARITHMETIC");
-    if (!e || !*e || !std::strcmp(e, "hybrid")) return KR_FLAG_HYBRID;
+    if (!e || !*e) return integrator == KR_RK45 ? 0 : KR_FLAG_HYBRID;
+    if (!std::strcmp(e, "hybrid")) return KR_FLAG_HYBRID;
     if (!std::strcmp(e, "strict")) return 0;
     if (!std::strcmp(e, "fast")) return KR_FLAG_FAST_MATH;
     throw std::invalid_argument(std::string("KRTRACE_ARITHMETIC: expected hybrid, strict or fast, got '") + e + "'");
@@ -108,7 +111,7 @@ void Raytracer<T>::fill_params(void* out, Integrator method, T r_max, int stepli
     p->integrator = static_cast<int>(method);   // Euler, RK4, RK45 == KR_EULER, KR_RK4, KR_RK45
     p->stop_kind = KR_STOP_THETA;
     p->steplim = steplim;                        // <= 0 selects STEPLIM / RK45_STEPLIM inside the library
-    p->flags = arithmetic_flags();
+    p->flags = arithmetic_flags(p->integrator);
 }
 
 template <typename T>

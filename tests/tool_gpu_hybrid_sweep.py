@@ -3,7 +3,7 @@
 For a set of sources (heights, spins, off-axis positions, orbiting sources, image planes at several inclinations) the compiled
 reference traces ~1e6 rays on the host cores and the HIP path traces the same initial rays in hybrid and in strict mode; per
 configuration: rays whose integer outcome (status, steps, flips, crossings) differs, rays beyond 1e-9, strict-side ray count.
-usage: python tests/tool_gpu_hybrid_sweep.py [rays=1e6]   -> one JSON line per configuration"""
+usage: python tests/tool_gpu_hybrid_sweep.py [rays=1e6] [rk4|rk45|euler]   -> one JSON line per configuration"""
 import json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -11,6 +11,7 @@ import oracle_lib as ol
 from raytrace_cpu_amd import api, capi
 
 rays_n = float(sys.argv[1]) if len(sys.argv) > 1 else 1e6
+METHOD = {"rk4": capi.RK4, "rk45": capi.RK45, "euler": capi.EULER}[sys.argv[2] if len(sys.argv) > 2 else "rk4"]
 d = 1.99 / (math.sqrt(rays_n) - 1.0)
 configs = []
 for spin, pos, V, tag in [(0.998, [0, 10, 1e-3, 1.5707], 0.0, "lamp h=10 (BASELINE)"), (0.998, [0, 3, 1e-3, 0.0], 0.0, "lamp h=3"),
@@ -25,16 +26,18 @@ for incl, spin in [(80.0, 0.998), (30.0, 0.998), (60.0, 0.5), (5.0, 0.9)]:
     configs.append(("ip", f"image plane incl={incl} a={spin} odd grid", ol.imageplane_spec(10000.0, incl, -30.0, 30.0, 60.0 / N, -30.0, 30.0, 60.0 / N, spin), spin, 0.0))
 configs.append(("ip", "image plane incl=80 even grid (pixel at 0,0)", ol.imageplane_spec(10000.0, 80.0, -30.0, 30.0, 60.0 / (N - 1), -30.0, 30.0, 60.0 / (N - 1), 0.998), 0.998, 0.0))
 
+if METHOD == capi.RK45:      # the reference's RK45 spends 1e5 steps on every captured ray: keep the sweep short (and off the (0,0) pixel, where it hangs)
+    configs = [c for c in configs if c[1] in ("lamp h=10 (BASELINE)", "lamp h=3", "lamp h=5 a=0.5", "off-axis theta=pi/4", "image plane incl=80.0 a=0.998 odd grid", "image plane incl=30.0 a=0.998 odd grid")]
 for kind, tag, spec, spin, V in configs:
     src = ol.RefSource(spec)
     if kind == "ps":
         src.lib.ref_redshift_start(src.h, V, 0, 0)
         p = capi.default_params(spin)
-        p.integrator, p.r_max = capi.RK4, 1000.0
+        p.integrator, p.r_max = METHOD, 1000.0
     else:
         src.lib.ref_redshift_start(src.h, 0.0, 1, 0)
         p = capi.default_params(-spin)
-        p.integrator, p.r_max = capi.RK4, 11000.0
+        p.integrator, p.r_max = METHOD, 11000.0
     init = src.snapshot()
     t0 = time.perf_counter()
     src.run(p)
@@ -43,7 +46,8 @@ for kind, tag, spec, spin, V in configs:
     src.close()
     valid = want["steps"] != -1
     row = {"config": tag, "rays": int(valid.sum()), "cpu_s": round(cpu_s, 2)}
-    for mode, flags in (("hybrid", capi.FLAG_HYBRID), ("strict", 0)):
+    modes = (("hybrid", capi.FLAG_HYBRID), ("strict", 0)) + ((("strict_iterate_all", capi.FLAG_RK45_ITERATE_ALL),) if METHOD == capi.RK45 else ())
+    for mode, flags in modes:
         got, st = api.trace(capi.copy_params(p, flags=flags), init)
         ints = np.zeros(len(init), dtype=bool)
         for k in ("status", "steps", "rdot_flips", "equatorial_crossings"):
