@@ -109,3 +109,15 @@ def test_bench_refuses_to_run_without_gpu():
         pytest.skip("a GPU is present")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout) and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_header_is_valid_c99_and_links_from_c(tmp_path):
+    """include/kr_trace.h from a C translation unit (gcc -std=c99 -pedantic-errors), linked against libkrtrace.so."""
+    import subprocess
+    exe = tmp_path / "abi_c_check"
+    csrc = os.path.join(ROOT, "raytrace_cpu_amd", "csrc")
+    subprocess.run(["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-o", str(exe), os.path.join(ROOT, "tests", "cpp", "abi_c_check.c"),
+                    "-L" + csrc, "-lkrtrace", "-Wl,-rpath," + csrc], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sizeof(ray_f64) 144 sizeof(ray_f32) 84" in r.stdout and "rays 5167" in r.stdout and "horizon 1.0632139225171164" in r.stdout
