@@ -116,3 +116,17 @@ def test_division_by_a_uniform_constant_is_correctly_rounded(krlib):
         got = probe(17, a, np.full_like(a, b))
         want = a / b
         assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), b
+
+
+def test_fifth_root_of_the_step_controller(krlib):
+    """kr_device.hpp::fifth_root_for_controller: within 1.5 ulp of x**0.2 where the DOPRI5 controller can tell (its factor is clamped to
+    [0.1, 5], i.e. x in [1.7e-5, 5.3e3]); outside, whatever saturates the clamp the same way; NaN propagates."""
+    rng = np.random.default_rng(13)
+    x = np.concatenate([10.0 ** rng.uniform(-6, 6, 1_000_000), rng.uniform(0.5, 2.0, 500_000), [1.0, 32.0, 1e-5, 1e10, 1e-300, 1e300]])
+    got = probe(18, x)
+    inside = (x >= 1e-6) & (x <= 1e6)
+    assert ulps(got[inside], x[inside] ** 0.2).max() <= 1.0      # numpy's pow with the same double exponent 0.2 (not the exact 5th root)
+    fac = lambda y: np.clip(0.9 * y, 0.1, 5.0)
+    assert np.array_equal(fac(got[~inside]), fac(x[~inside] ** 0.2))          # 0.1 or 5 either way
+    assert np.isnan(probe(18, np.array([np.nan]))[0])
+    assert probe(18, np.array([1.0]))[0] == 1.0 and abs(probe(18, np.array([32.0]))[0] - 32.0 ** 0.2) <= 4.5e-16
