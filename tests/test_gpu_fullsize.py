@@ -110,3 +110,30 @@ def test_full_size_properties(krlib, flags):
         np.testing.assert_allclose(parts, whole, rtol=1e-11)                      # sums: order of addition only
     finally:
         lib.kr_free(d_rays)
+
+
+def test_rk45_creep_mode_at_scale(krlib):
+    """1e6 rays of the BASELINE source under RK45, strict arithmetic: carrying the ~2000 creeping captured rays to the step limit
+    from k1 alone (default) against iterating all of their 1e5 steps (KR_FLAG_RK45_ITERATE_ALL) -- every ray's r, theta, status,
+    step count and counters bit-identical; t and phi of the creeping rays within 1e-10; everything else bit-identical."""
+    spec = _spec(1.99 / (math.sqrt(1e6) - 1.0))
+    init = api.pointsource_init(spec)
+    api.redshift_start(gc.SPIN, 0.0, 0, 0, init)
+    p = capi.default_params(gc.SPIN)
+    p.integrator, p.r_max = capi.RK45, 1000.0
+    quick, st = api.trace(p, init)
+    full, st0 = api.trace(capi.copy_params(p, flags=capi.FLAG_RK45_ITERATE_ALL), init)
+    assert st0["rk45_extrapolated_steps"] == 0 and st["rk45_extrapolated_steps"] > 1e8
+    assert st["steps_total"] == st0["steps_total"] and st["rk45_attempts"] == st0["rk45_attempts"] and st["rk45_rejects"] == st0["rk45_rejects"]
+    touched = np.zeros(len(init), dtype=bool)
+    for f in quick.dtype.names:
+        a, b = quick[f], full[f]
+        same = (a == b) | (np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64)))
+        if f in ("t", "phi", "pt", "pr", "ptheta", "pphi"):
+            touched |= ~same
+        else:
+            assert same.all(), f
+    lim = (full["status"] & capi.STATUS_STEPLIM) != 0
+    assert 500 < touched.sum() <= lim.sum() and not (touched & ~lim).any()
+    for f in ("t", "phi"):
+        np.testing.assert_allclose(quick[f][touched], full[f][touched], rtol=1e-10)
