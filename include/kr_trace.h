@@ -214,7 +214,13 @@ double      kr_disc_velocity(double r, double a, int sign); /* disc_velocity(), 
 int64_t     kr_pointsource_count(const kr_pointsource* s, int32_t* n_cosalpha, int32_t* n_beta);   /* pointsource.cpp:12,16-17 */
 int64_t     kr_imageplane_count(const kr_imageplane* s, int32_t* nx, int32_t* ny);                 /* imageplane.cpp:12-14 */
 
-/* ---- the hot path: Raytracer<T>::run_raytrace, both overloads (raytracer.cpp:63-127, 972-1034) -- */
+/* ---- the hot path: Raytracer<T>::run_raytrace, both overloads (raytracer.cpp:63-127, 972-1034) --
+ * Host-pointer forms stage through a private device buffer and return when rays[] is final.  *_dev forms take a device
+ * pointer and a hipStream_t (NULL: the default stream): work is enqueued on that stream and, with stats == NULL, the call
+ * returns before it has finished -- except that a split launch (KR_FLAG_HYBRID, or flags = 0 with >= 2^18 rays) first
+ * synchronises the stream once to read the size of its side launch.  Per device the library keeps one set of queue counters,
+ * index lists and events: trace calls for one device must not overlap in time (one caller thread, one stream at a time);
+ * the reference's caller is single-threaded too. */
 int kr_trace_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, kr_stats* stats);
 int kr_trace_f32(const kr_params* p, kr_ray_f32* rays, int64_t n, kr_stats* stats);
 int kr_trace_dev_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, kr_stats* stats);
