@@ -170,12 +170,19 @@ class EmissivityWorkload:
         self.result_words = 5 * NR + 1
         self.describe = (f"PointSource emissivity lamp-post h=10 a=0.998 V=0, {args.integrator.upper()}, theta_max=pi/2 r_max=1000 "
                          f"(BASELINE configs[1]); grid {self.n_ca}x{self.n_b} per GPU")
-        self.pipeline = "pointsource_init+redshift_start+trace+range_phi+redshift+emissivity_histogram"
+        self.fused = not args.separate_passes
+        self.pipeline = ("[pointsource_init+redshift_start]+trace+[range_phi+redshift+emissivity_histogram] ([..] = one fused pass each)" if self.fused
+                         else "pointsource_init+redshift_start+trace+range_phi+redshift+emissivity_histogram")
         self.sharding = f"row-cyclic over {world} rank(s)"
 
     def step(self, d_rays, d_res, stream):
         lib, capi, vp = self.lib, self.capi, C.c_void_p
         n = self.n
+        if self.fused:      # same per-ray arithmetic, two passes over the records instead of five (tests: test_fused_pipeline_ends_...)
+            capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(self.spec), 0, 1, 0.0, 0, 0, vp(d_rays), n, vp(stream)), "init_emit")
+            st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
+            capi.check(lib, lib.kr_post_emissivity_dev_f64(SPIN, -1.0, 0, 0, 0, -math.pi, math.pi, C.byref(self.bins), vp(d_rays), n, vp(d_res), vp(stream)), "post")
+            return st
         capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(self.spec), vp(d_rays), n, vp(stream)), "init")
         capi.check(lib, lib.kr_redshift_start_dev_f64(SPIN, 0.0, 0, 0, vp(d_rays), n, vp(stream)), "redshift_start")
         st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
@@ -309,6 +316,7 @@ def main():
                     help="hybrid (KR_FLAG_HYBRID: strict for ill-conditioned rays, fast for the rest), strict (flags = 0), fast (KR_FLAG_FAST_MATH); "
                          "auto = hybrid for euler / rk4, strict for rk45 (what the host mirror of the class API does)")
     ap.add_argument("--fast-math", action="store_true", help="same as --arithmetic fast")
+    ap.add_argument("--separate-passes", action="store_true", help="emissivity: the five O(N) passes one kernel each instead of the two fused ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-math-extra", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=float, default=0)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 5
+#define KR_ABI_VERSION 6
 
 /* error codes */
 #define KR_OK          0
@@ -253,6 +253,16 @@ int kr_imageplane_init_dev_f64(const kr_imageplane* s, void* d_rays, int64_t n, 
  * Rank r of R uses first = r, stride = R: ray-cyclic sharding, nothing else has to be exchanged before the reducers. */
 int kr_pointsource_init_strided_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, void* d_rays, int64_t count, void* stream);
 int kr_imageplane_init_strided_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, void* d_rays, int64_t count, void* stream);
+
+/* ---- fused ends of the emissivity pipeline (device-resident callers): the same per-ray arithmetic as the separate passes, one
+ * pass over the records instead of two / three.  kr_pointsource_init_emit = PointSource ctor + redshift_start(V, reverse,
+ * projradius) (pointsource.cpp:11-64 + raytracer.cpp:342-417), strided like kr_pointsource_init_strided_dev_f64;
+ * kr_post_emissivity = range_phi(lo, hi) + redshift(V, reverse, projradius, motion) + the histogram of kr_reduce_emissivity_dev_f64
+ * (raytracer.cpp:603-622, :420-553, emissivity.cpp:96-126); rays[] ends up exactly as after the separate calls. */
+int kr_pointsource_init_emit_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d_rays, int64_t count,
+                                     void* stream);
+int kr_post_emissivity_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d_rays, int64_t n,
+                               void* d_hist, void* stream);
 
 /* ---- reducers of the two target apps --------------------------------------------------------- */
 /* emissivity.cpp:96-126.  Outputs (length nr each): count, flux, emis, sum_redshift, sum_time -- the raw

@@ -99,16 +99,13 @@ try {
     krapp::DeviceBuffer rays(n * (int64_t) sizeof(kr_ray_f64));
     krapp::DeviceBuffer hist((5 * (int64_t) Nr + 1) * (int64_t) sizeof(double));
     hist.zero();
-    krapp::check(kr_pointsource_init_dev_f64(&src, rays.get(), n, nullptr), "pointsource_init");
-    krapp::check(kr_redshift_start_dev_f64(spin, V, 0, 0, rays.get(), n, nullptr), "redshift_start");
+    krapp::check(kr_pointsource_init_emit_dev_f64(&src, 0, 1, V, 0, 0, rays.get(), n, nullptr), "pointsource_init + redshift_start");
     krapp::check(kr_synchronize(nullptr), "sync");
     const double ms_init = clock.lap_ms();
     kr_stats st;
     krapp::check(kr_trace_dev_f64(&p, rays.get(), n, nullptr, &st), "trace");
     const double ms_trace = clock.lap_ms();
-    krapp::check(kr_range_phi_dev_f64(-1 * M_PI, M_PI, rays.get(), n, nullptr), "range_phi");
-    krapp::check(kr_redshift_dev_f64(spin, -1.0, 0, 0, 0, rays.get(), n, nullptr), "redshift");
-    krapp::check(kr_reduce_emissivity_dev_f64(&bins, rays.get(), n, hist.get(), nullptr), "reduce");
+    krapp::check(kr_post_emissivity_dev_f64(spin, -1.0, 0, 0, 0, -1 * M_PI, M_PI, &bins, rays.get(), n, hist.get(), nullptr), "range_phi + redshift + histogram");
     vector<double> h(5 * (size_t) Nr + 1);
     krapp::check(kr_memcpy_d2h(h.data(), hist.get(), (int64_t) (h.size() * sizeof(double))), "d2h");
     const double ms_post = clock.lap_ms();

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -133,6 +133,8 @@ PROTOTYPES = {
     "kr_imageplane_init_strided_dev_f64": (_int, [P(ImagePlaneSpec), _i64, _i64, _vp, _i64, _vp]),
     "kr_reduce_emissivity_f64": (_int, [P(EmisBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
     "kr_reduce_emissivity_dev_f64": (_int, [P(EmisBins), _vp, _i64, _vp, _vp]),
+    "kr_pointsource_init_emit_dev_f64": (_int, [P(PointSourceSpec), _i64, _i64, _dbl, _int, _int, _vp, _i64, _vp]),
+    "kr_post_emissivity_dev_f64": (_int, [_dbl, _dbl, _int, _int, _int, _dbl, _dbl, P(EmisBins), _vp, _i64, _vp, _vp]),
     "kr_reduce_image_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
     "kr_reduce_image_dev_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp]),
     "kr_reduce_return_f64": (_int, [P(ReturnBins), _vp, _i64, P(_dbl * 4)]),

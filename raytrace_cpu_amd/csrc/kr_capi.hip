@@ -25,6 +25,9 @@ int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st);
 int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st);
 int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st);
 int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st);
+int post_emissivity_dev(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d, int64_t n,
+                        void* d_hist, hipStream_t st);
+int pointsource_init_emit_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, double V, int reverse, int projradius, hipStream_t st);
 int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st);
 int reduce_return_dev(const kr_return_bins* b, const void* d, int64_t n, void* d_out4, hipStream_t st);
 int arith_probe_dev(int op, const double* a, const double* b, double* out, int64_t n);
@@ -305,6 +308,21 @@ int kr_pointsource_init_strided_dev_f64(const kr_pointsource* s, int64_t first, 
     if (!s) { set_error("kr_pointsource_init: null spec"); return KR_EINVAL; }
     int rc = require_device();
     return rc != KR_OK ? rc : pointsource_init_dev(s, d, count, first, stride, (hipStream_t) st);
+}
+// fused pipeline ends (device-resident callers): source constructor + redshift_start() in one pass ...
+int kr_pointsource_init_emit_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d, int64_t count, void* st)
+{
+    if (!s) { set_error("kr_pointsource_init_emit: null spec"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : pointsource_init_emit_dev(s, d, count, first, stride, V, reverse, projradius, (hipStream_t) st);
+}
+// ... and range_phi() + redshift() + the emissivity histogram in one pass
+int kr_post_emissivity_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d, int64_t n,
+                               void* d_hist, void* st)
+{
+    if (!b || !d_hist) { set_error("kr_post_emissivity: null argument"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : post_emissivity_dev(spin, V, reverse, projradius, motion, lo, hi, b, d, n, d_hist, (hipStream_t) st);
 }
 int kr_imageplane_init_strided_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, void* d, int64_t count, void* st)
 {

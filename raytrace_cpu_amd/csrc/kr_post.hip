@@ -77,6 +77,18 @@ KR_DEV double keplerian_V(double a, double r, double theta, bool projradius)
 // ---- redshift_start (raytracer.cpp:342-417) ------------------------------------------------------------
 // V is a by-value parameter that the reference's loop overwrites when it equals -1, so the orbital velocity
 // computed at the FIRST record (index 0, valid or not) is used for every ray.
+KR_DEV double emit_value(const kr_ray_f64& ray, double spin, double a, double V, int reverse)
+{
+    const double r = ray.r, theta = ray.theta;
+    const Metric m = kerr_metric(r, theta, a);
+    const double et[4] = {(1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu), 0, 0,
+                          (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu)};
+    double p[4];
+    momentum<double>(p[0], p[1], p[2], p[3], ray.k, ray.h, ray.Q, ray.rdot_sign, ray.thetadot_sign, r, theta, spin);
+    if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
+    return energy_dot(m, et, p);
+}
+
 __global__ void __launch_bounds__(kBlock)
 redshift_start_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double V, int reverse, int projradius)
 {
@@ -84,42 +96,45 @@ redshift_start_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, d
     if (V == -1) V = keplerian_V(a, rays[0].r, rays[0].theta, projradius != 0);
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
         kr_ray_f64* ray = &rays[i];
-        const double r = ray->r, theta = ray->theta;
-        const Metric m = kerr_metric(r, theta, a);
-        const double et[4] = {(1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu), 0, 0,
-                              (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu)};
-        double p[4];
-        momentum<double>(p[0], p[1], p[2], p[3], ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, r, theta, spin);
-        if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
-        ray->emit = energy_dot(m, et, p);
+        kr_ray_f64 v;
+        v.r = ray->r; v.theta = ray->theta; v.k = ray->k; v.h = ray->h; v.Q = ray->Q; v.rdot_sign = ray->rdot_sign; v.thetadot_sign = ray->thetadot_sign;
+        ray->emit = emit_value(v, spin, a, V, reverse);
     }
 }
 
 // ---- redshift(V, ...) (raytracer.cpp:420-447, :480-553) ----------------------------------------------
+KR_DEV double redshift_value(const kr_ray_f64& ray, double spin, double V_in, int reverse, int projradius, int motion)
+{
+    const double a = reverse ? -1 * spin : spin;
+    const double r = ray.r, theta = ray.theta;
+    const Metric m = kerr_metric(r, theta, a);
+    double V = V_in;
+    double et[4] = {0, 0, 0, 0};
+    if (motion == 0) {
+        if (V == -1) V = keplerian_V(a, r, theta, projradius != 0);
+        et[0] = (1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
+        et[3] = (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
+    } else if (motion == 1) {
+        if (V < 0) V = kr_abs(V) * (r * r - 2 * r + spin + spin) / (r * r + spin * spin);   // sic, :531
+        et[0] = 1. / kr_sqrt(m.g00 + m.g11 * V * V);
+        et[1] = V * et[0];
+    }
+    double p[4];
+    momentum<double>(p[0], p[1], p[2], p[3], ray.k, ray.h, ray.Q, ray.rdot_sign, ray.thetadot_sign, r, theta, spin);
+    if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
+    const double recv = energy_dot(m, et, p);
+    return reverse ? recv / ray.emit : ray.emit / recv;
+}
+
 __global__ void __launch_bounds__(kBlock)
 redshift_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double V_in, int reverse, int projradius, int motion)
 {
-    const double a = reverse ? -1 * spin : spin;
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
         kr_ray_f64* ray = &rays[i];
-        const double r = ray->r, theta = ray->theta;
-        const Metric m = kerr_metric(r, theta, a);
-        double V = V_in;
-        double et[4] = {0, 0, 0, 0};
-        if (motion == 0) {
-            if (V == -1) V = keplerian_V(a, r, theta, projradius != 0);
-            et[0] = (1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
-            et[3] = (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
-        } else if (motion == 1) {
-            if (V < 0) V = kr_abs(V) * (r * r - 2 * r + spin + spin) / (r * r + spin * spin);   // sic, :531
-            et[0] = 1. / kr_sqrt(m.g00 + m.g11 * V * V);
-            et[1] = V * et[0];
-        }
-        double p[4];
-        momentum<double>(p[0], p[1], p[2], p[3], ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, r, theta, spin);
-        if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
-        const double recv = energy_dot(m, et, p);
-        ray->redshift = reverse ? recv / ray->emit : ray->emit / recv;
+        kr_ray_f64 v;
+        v.r = ray->r; v.theta = ray->theta; v.k = ray->k; v.h = ray->h; v.Q = ray->Q; v.rdot_sign = ray->rdot_sign; v.thetadot_sign = ray->thetadot_sign;
+        v.emit = ray->emit;
+        ray->redshift = redshift_value(v, spin, V_in, reverse, projradius, motion);
     }
 }
 
@@ -144,14 +159,20 @@ redshift_dest_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, in
 }
 
 // ---- range_phi (raytracer.cpp:603-622): repeated +-2pi like the reference, so the result is bit-identical ----
+KR_DEV double range_phi_value(double phi, int steps, double lo, double hi)
+{
+    if (kr_abs(phi) > 1000 || phi != phi || !(steps > 0)) return phi;
+    while (phi >= hi) phi -= 2 * kPi;
+    while (phi < lo) phi += 2 * kPi;
+    return phi;
+}
+
 __global__ void __launch_bounds__(kBlock) range_phi_kernel(kr_ray_f64* __restrict__ rays, long long n, double lo, double hi)
 {
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
-        double phi = rays[i].phi;
-        if (kr_abs(phi) > 1000 || phi != phi || !(rays[i].steps > 0)) continue;
-        while (phi >= hi) phi -= 2 * kPi;
-        while (phi < lo) phi += 2 * kPi;
-        rays[i].phi = phi;
+        const double phi = rays[i].phi;
+        const double wrapped = range_phi_value(phi, rays[i].steps, lo, hi);
+        if (!(wrapped == phi) && wrapped == wrapped) rays[i].phi = wrapped;
     }
 }
 
@@ -169,13 +190,9 @@ __global__ void __launch_bounds__(kBlock) calculate_momentum_kernel(kr_ray_f64* 
 // ---- PointSource ctor: Raytracer ctor (steps=-1, status=0, raytracer.cpp:45-49) + init_pointsource
 //      (pointsource.cpp:30-64) + calculate_constants (raytracer.cpp:625-676).  Fields the reference leaves
 //      indeterminate are zeroed. ------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, int n_cosalpha, int n_beta, long long first, long long stride)
+KR_DEV kr_ray_f64 pointsource_ray(const kr_pointsource& s, long long n_grid, int n_beta, long long ix)
 {
-    const long long n_grid = (long long) n_cosalpha * n_beta;
-    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
-        const long long ix = first + slot * stride;       // index in the source's own ray array
-        kr_ray_f64 ray;
+    kr_ray_f64 ray;
         memset(&ray, 0, sizeof(ray));
         ray.steps = -1;
         if (ix < n_grid) {
@@ -224,6 +241,32 @@ pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsour
                 ray.thetadot_sign = (thetadot > 0) ? 1 : -1;
             }
         }
+    return ray;
+}
+
+__global__ void __launch_bounds__(kBlock)
+pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, int n_cosalpha, int n_beta, long long first, long long stride)
+{
+    const long long n_grid = (long long) n_cosalpha * n_beta;
+    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock)
+        rays[slot] = pointsource_ray(s, n_grid, n_beta, first + slot * stride);
+}
+
+// ---- fused prologue of the emissivity pipeline: PointSource ctor + redshift_start() in ONE pass (the record is written once,
+//      with its `emit`); same per-ray functions as the two separate kernels, V == -1 resolved from record 0 as there ----------
+__global__ void __launch_bounds__(kBlock)
+pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, int n_cosalpha, int n_beta, long long first, long long stride,
+                             double V, int reverse, int projradius)
+{
+    const long long n_grid = (long long) n_cosalpha * n_beta;
+    const double a = reverse ? -1 * s.spin : s.spin;
+    if (V == -1) {
+        const kr_ray_f64 r0 = pointsource_ray(s, n_grid, n_beta, first);
+        V = keplerian_V(a, r0.r, r0.theta, projradius != 0);
+    }
+    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
+        kr_ray_f64 ray = pointsource_ray(s, n_grid, n_beta, first + slot * stride);
+        ray.emit = emit_value(ray, s.spin, a, V, reverse);
         rays[slot] = ray;
     }
 }
@@ -295,6 +338,25 @@ imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane
 // LDS holds one private copy per workgroup when it fits (5*nr+1 doubles); flushed with global f64 atomics.
 constexpr int kMaxLdsBins = 1024;
 
+// one ray's contribution to the radial histogram (emissivity.cpp:96-126); acc: LDS copy or the global histogram
+KR_DEV void emissivity_accumulate(double* acc, const kr_emis_bins& b, double log_dr, int steps, double r, double theta, double g, double t)
+{
+    if (!(steps > 0)) return;
+    const int nr = b.nr;
+    const double z = r * kr_cos(theta);         // cartesian(), kerr.h:55
+    if (z < 1E-2 && g > 0 && r >= b.r_isco) {
+        const int ir = b.logbin ? (int) (kr_log(r / b.r_min) / log_dr) : (int) ((r - b.r_min) / b.dr);
+        if (ir >= 0 && ir < nr) {
+            atomicAdd(&acc[ir], 1.0);
+            atomicAdd(&acc[nr + ir], 1 / (b.num_primary_rays * kr_pow(g, 1.0)));
+            atomicAdd(&acc[2 * nr + ir], 1 / kr_pow(g, b.gamma));
+            atomicAdd(&acc[3 * nr + ir], g);
+            atomicAdd(&acc[4 * nr + ir], t);
+        }
+        atomicAdd(&acc[5 * nr], 1.0);
+    }
+}
+
 template <bool USE_LDS>
 __global__ void __launch_bounds__(kBlock)
 reduce_emissivity_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_emis_bins b, double* __restrict__ hist)
@@ -310,20 +372,44 @@ reduce_emissivity_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_em
     const double log_dr = kr_log(b.dr);
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
         const kr_ray_f64* ray = &rays[i];
-        if (!(ray->steps > 0)) continue;
-        const double r = ray->r, g = ray->redshift;
-        const double z = r * kr_cos(ray->theta);         // cartesian(), kerr.h:55
-        if (z < 1E-2 && g > 0 && r >= b.r_isco) {
-            const int ir = b.logbin ? (int) (kr_log(r / b.r_min) / log_dr) : (int) ((r - b.r_min) / b.dr);
-            if (ir >= 0 && ir < nr) {
-                atomicAdd(&acc[ir], 1.0);
-                atomicAdd(&acc[nr + ir], 1 / (b.num_primary_rays * kr_pow(g, 1.0)));
-                atomicAdd(&acc[2 * nr + ir], 1 / kr_pow(g, b.gamma));
-                atomicAdd(&acc[3 * nr + ir], g);
-                atomicAdd(&acc[4 * nr + ir], ray->t);
-            }
-            atomicAdd(&acc[5 * nr], 1.0);
-        }
+        emissivity_accumulate(acc, b, log_dr, ray->steps, ray->r, ray->theta, ray->redshift, ray->t);
+    }
+    if (USE_LDS) {
+        __syncthreads();
+        for (int w = threadIdx.x; w < words; w += kBlock)
+            if (lds[w] != 0) atomicAdd(&hist[w], lds[w]);
+    }
+}
+
+// ---- fused epilogue of the emissivity pipeline: range_phi -> redshift -> histogram in ONE pass over the records
+//      (emissivity.cpp:93-126: the three O(N) steps after run_raytrace).  Same per-ray functions as the separate
+//      kernels, so rays[] and the integer bin counts are bit-identical to running them one after another. -------------
+template <bool USE_LDS>
+__global__ void __launch_bounds__(kBlock)
+post_emissivity_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double V, int reverse, int projradius, int motion, double lo, double hi,
+                       kr_emis_bins b, double* __restrict__ hist)
+{
+    __shared__ double lds[USE_LDS ? (5 * kMaxLdsBins + 1) : 1];
+    const int nr = b.nr;
+    const int words = 5 * nr + 1;
+    if (USE_LDS) {
+        for (int w = threadIdx.x; w < words; w += kBlock) lds[w] = 0;
+        __syncthreads();
+    }
+    double* acc = USE_LDS ? lds : hist;
+    const double log_dr = kr_log(b.dr);
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        kr_ray_f64* ray = &rays[i];
+        kr_ray_f64 v;
+        v.r = ray->r; v.theta = ray->theta; v.k = ray->k; v.h = ray->h; v.Q = ray->Q; v.rdot_sign = ray->rdot_sign; v.thetadot_sign = ray->thetadot_sign;
+        v.emit = ray->emit;
+        const int steps = ray->steps;
+        const double phi = ray->phi;
+        const double wrapped = range_phi_value(phi, steps, lo, hi);
+        if (!(wrapped == phi) && wrapped == wrapped) ray->phi = wrapped;
+        const double g = redshift_value(v, spin, V, reverse, projradius, motion);
+        ray->redshift = g;
+        emissivity_accumulate(acc, b, log_dr, steps, v.r, v.theta, g, ray->t);
     }
     if (USE_LDS) {
         __syncthreads();
@@ -503,6 +589,18 @@ int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t fi
     return KR_OK;
 }
 
+int pointsource_init_emit_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, double V, int reverse, int projradius, hipStream_t st)
+{
+    int32_t nc = 0, nb = 0;
+    kr_pointsource_count(s, &nc, &nb);
+    if (first < 0 || stride < 1) { set_error("kr_pointsource_init_emit: bad first/stride"); return KR_EINVAL; }
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(pointsource_init_emit_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nc, nb, (long long) first,
+                       (long long) stride, V, reverse, projradius);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
 int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st)
 {
     int32_t nx = 0, ny = 0;
@@ -525,6 +623,22 @@ int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void*
         hipLaunchKernelGGL(reduce_emissivity_kernel<true>, dim3(grid), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_hist);
     else
         hipLaunchKernelGGL(reduce_emissivity_kernel<false>, dim3(grid), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_hist);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int post_emissivity_dev(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d, int64_t n,
+                        void* d_hist, hipStream_t st)
+{
+    if (b->nr <= 0) { set_error("kr_post_emissivity: nr must be positive"); return KR_EINVAL; }
+    if (n <= 0) return KR_OK;
+    const int grid = grid_for(n, 256 * 4);
+    if (b->nr <= kMaxLdsBins)
+        hipLaunchKernelGGL(post_emissivity_kernel<true>, dim3(grid), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, V, reverse, projradius, motion, lo, hi, *b,
+                           (double*) d_hist);
+    else
+        hipLaunchKernelGGL(post_emissivity_kernel<false>, dim3(grid), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, V, reverse, projradius, motion, lo, hi, *b,
+                           (double*) d_hist);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }

@@ -442,3 +442,48 @@ def test_rk45_creep_mode_reproduces_iteration(krlib):
     assert moved.sum() > 0 and not (moved & ~lim).any()                       # only step-limit rays were touched
     for f in ("t", "phi"):
         np.testing.assert_allclose(fast_way[f][moved], slow_way[f][moved], rtol=1e-10)
+
+
+def test_fused_pipeline_ends_equal_the_separate_passes(krlib):
+    """kr_pointsource_init_emit_dev_f64 == init + redshift_start, kr_post_emissivity_dev_f64 == range_phi + redshift + reduce:
+    rays bit-identical, histogram counts identical, sums equal up to the order of the atomic additions."""
+    import bench
+    lib, vp = krlib, C.c_void_p
+    spec = bench.make_spec(capi, bench.grid_spacing_for(2e5))
+    n = lib.kr_pointsource_count(C.byref(spec), None, None)
+    bins = gc.emis_bins(spec, nr=100)
+    words = 5 * bins.nr + 1
+    p = capi.default_params(gc.SPIN)
+    p.integrator, p.r_max = capi.RK4, 1000.0
+    bufs = []
+    for fused in (False, True):
+        d_rays, d_hist = vp(), vp()
+        capi.check(lib, lib.kr_malloc(C.byref(d_rays), n * 144), "malloc")
+        capi.check(lib, lib.kr_malloc(C.byref(d_hist), words * 8), "malloc")
+        capi.check(lib, lib.kr_memset(d_hist, 0, words * 8), "memset")
+        if fused:
+            capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(spec), 0, 1, 0.0, 0, 0, d_rays, n, None), "init_emit")
+        else:
+            capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(spec), d_rays, n, None), "init")
+            capi.check(lib, lib.kr_redshift_start_dev_f64(gc.SPIN, 0.0, 0, 0, d_rays, n, None), "redshift_start")
+        start = np.zeros(n, dtype=capi.RAY_F64)
+        capi.check(lib, lib.kr_memcpy_d2h(start.ctypes.data_as(vp), d_rays, n * 144), "d2h")
+        capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, None), "trace")
+        if fused:
+            capi.check(lib, lib.kr_post_emissivity_dev_f64(gc.SPIN, -1.0, 0, 0, 0, -np.pi, np.pi, C.byref(bins), d_rays, n, d_hist, None), "post")
+        else:
+            capi.check(lib, lib.kr_range_phi_dev_f64(-np.pi, np.pi, d_rays, n, None), "range_phi")
+            capi.check(lib, lib.kr_redshift_dev_f64(gc.SPIN, -1.0, 0, 0, 0, d_rays, n, None), "redshift")
+            capi.check(lib, lib.kr_reduce_emissivity_dev_f64(C.byref(bins), d_rays, n, d_hist, None), "reduce")
+        end = np.zeros(n, dtype=capi.RAY_F64)
+        hist = np.zeros(words)
+        capi.check(lib, lib.kr_memcpy_d2h(end.ctypes.data_as(vp), d_rays, n * 144), "d2h")
+        capi.check(lib, lib.kr_memcpy_d2h(hist.ctypes.data_as(vp), d_hist, words * 8), "d2h")
+        lib.kr_free(d_rays)
+        lib.kr_free(d_hist)
+        bufs.append((start, end, hist))
+    (s0, e0, h0), (s1, e1, h1) = bufs
+    assert ol.rays_equal_bitwise(s0, s1) == [] and ol.rays_equal_bitwise(e0, e1) == []
+    assert h0[5 * bins.nr] > 1e5
+    np.testing.assert_array_equal(h0[:bins.nr], h1[:bins.nr])
+    np.testing.assert_allclose(h0, h1, rtol=1e-12)
