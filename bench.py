@@ -224,12 +224,19 @@ class ImagePlaneWorkload:
         self.result_words = 7 * N * N + 1
         self.describe = (f"ImagePlane disc image dist=1e4 incl=80 a=0.998 x,y in +-30, {nx}x{ny} rays, img {N}x{N}, {args.integrator.upper()}, "
                          f"r_max=1.1*dist (BASELINE configs[3])")
-        self.pipeline = "imageplane_init+redshift_start+trace+redshift+range_phi+image_planes"
+        self.fused = not args.separate_passes
+        self.pipeline = ("[imageplane_init+redshift_start]+trace+[redshift+range_phi+image_planes] ([..] = one fused pass each)" if self.fused
+                         else "imageplane_init+redshift_start+trace+redshift+range_phi+image_planes")
         self.sharding = f"ray-cyclic over {world} rank(s)"
 
     def step(self, d_rays, d_res, stream):
         lib, capi, vp = self.lib, self.capi, C.c_void_p
         n = self.n
+        if self.fused:
+            capi.check(lib, lib.kr_imageplane_init_emit_dev_f64(C.byref(self.spec), self.first, self.stride, 0.0, 1, 0, vp(d_rays), n, vp(stream)), "init_emit")
+            st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
+            capi.check(lib, lib.kr_post_image_dev_f64(-SPIN, -1.0, 1, 0, 0, -math.pi, math.pi, C.byref(self.bins), vp(d_rays), n, vp(d_res), vp(stream)), "post")
+            return st
         capi.check(lib, lib.kr_imageplane_init_strided_dev_f64(C.byref(self.spec), self.first, self.stride, vp(d_rays), n, vp(stream)), "init")
         capi.check(lib, lib.kr_redshift_start_dev_f64(-SPIN, 0.0, 1, 0, vp(d_rays), n, vp(stream)), "redshift_start")
         st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
@@ -316,7 +323,7 @@ def main():
                     help="hybrid (KR_FLAG_HYBRID: strict for ill-conditioned rays, fast for the rest), strict (flags = 0), fast (KR_FLAG_FAST_MATH); "
                          "auto = hybrid for euler / rk4, strict for rk45 (what the host mirror of the class API does)")
     ap.add_argument("--fast-math", action="store_true", help="same as --arithmetic fast")
-    ap.add_argument("--separate-passes", action="store_true", help="emissivity: the five O(N) passes one kernel each instead of the two fused ones")
+    ap.add_argument("--separate-passes", action="store_true", help="emissivity / imageplane: the five O(N) passes one kernel each instead of the two fused ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-math-extra", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=float, default=0)

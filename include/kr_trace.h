@@ -261,6 +261,13 @@ int kr_imageplane_init_strided_dev_f64(const kr_imageplane* s, int64_t first, in
  * (raytracer.cpp:603-622, :420-553, emissivity.cpp:96-126); rays[] ends up exactly as after the separate calls. */
 int kr_pointsource_init_emit_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d_rays, int64_t count,
                                      void* stream);
+/* the same for the image pipeline: ImagePlane ctor + redshift_start(V, reverse, projradius) (imageplane.cpp:11-121; the negated spin
+ * of the ImagePlane is applied inside), and redshift(V, reverse, projradius, motion) + range_phi(lo, hi) + the seven planes of
+ * kr_reduce_image_dev_f64 (imageplane_disc_image.cpp:117-161; `spin` as stored by the Raytracer, i.e. negated) */
+int kr_imageplane_init_emit_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d_rays, int64_t count,
+                                    void* stream);
+int kr_post_image_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_image_bins* b, void* d_rays, int64_t n,
+                          void* d_planes, void* stream);
 int kr_post_emissivity_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d_rays, int64_t n,
                                void* d_hist, void* stream);
 

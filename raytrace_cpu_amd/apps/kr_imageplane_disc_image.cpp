@@ -98,16 +98,13 @@ try {
     krapp::DeviceBuffer rays(n * (int64_t) sizeof(kr_ray_f64));
     krapp::DeviceBuffer planes((7 * npix + 1) * (int64_t) sizeof(double));
     planes.zero();
-    krapp::check(kr_imageplane_init_dev_f64(&plane, rays.get(), n, nullptr), "imageplane_init");
-    krapp::check(kr_redshift_start_dev_f64(-spin, 0.0, 1, 0, rays.get(), n, nullptr), "redshift_start");
+    krapp::check(kr_imageplane_init_emit_dev_f64(&plane, 0, 1, 0.0, 1, 0, rays.get(), n, nullptr), "imageplane_init + redshift_start");
     krapp::check(kr_synchronize(nullptr), "sync");
     const double ms_init = clock.lap_ms();
     kr_stats st;
     krapp::check(kr_trace_dev_f64(&p, rays.get(), n, nullptr, &st), "trace");
     const double ms_trace = clock.lap_ms();
-    krapp::check(kr_redshift_dev_f64(-spin, -1.0, 1, 0, 0, rays.get(), n, nullptr), "redshift");
-    krapp::check(kr_range_phi_dev_f64(-1 * M_PI, M_PI, rays.get(), n, nullptr), "range_phi");
-    krapp::check(kr_reduce_image_dev_f64(&bins, rays.get(), n, planes.get(), nullptr), "reduce");
+    krapp::check(kr_post_image_dev_f64(-spin, -1.0, 1, 0, 0, -1 * M_PI, M_PI, &bins, rays.get(), n, planes.get(), nullptr), "redshift + range_phi + image planes");
     krapp::PinnedDoubles h(7 * npix + 1);     // 0.94 GB at 4096^2: page-locked, or the read-back runs at a tenth of the PCIe rate
     krapp::check(kr_memcpy_d2h(h.data(), planes.get(), h.size() * (int64_t) sizeof(double)), "d2h");
     const double ms_post = clock.lap_ms();

@@ -27,6 +27,10 @@ int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t firs
 int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st);
 int post_emissivity_dev(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d, int64_t n,
                         void* d_hist, hipStream_t st);
+int imageplane_init_emit_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, double spin, double V, int reverse, int projradius,
+                             hipStream_t st);
+int post_image_dev(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_image_bins* b, void* d, int64_t n,
+                   void* d_planes, hipStream_t st);
 int pointsource_init_emit_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, double V, int reverse, int projradius, hipStream_t st);
 int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st);
 int reduce_return_dev(const kr_return_bins* b, const void* d, int64_t n, void* d_out4, hipStream_t st);
@@ -323,6 +327,19 @@ int kr_post_emissivity_dev_f64(double spin, double V, int reverse, int projradiu
     if (!b || !d_hist) { set_error("kr_post_emissivity: null argument"); return KR_EINVAL; }
     int rc = require_device();
     return rc != KR_OK ? rc : post_emissivity_dev(spin, V, reverse, projradius, motion, lo, hi, b, d, n, d_hist, (hipStream_t) st);
+}
+int kr_imageplane_init_emit_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d, int64_t count, void* st)
+{
+    if (!s) { set_error("kr_imageplane_init_emit: null spec"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : imageplane_init_emit_dev(s, d, count, first, stride, -1 * s->spin, V, reverse, projradius, (hipStream_t) st);
+}
+int kr_post_image_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_image_bins* b, void* d, int64_t n,
+                          void* d_planes, void* st)
+{
+    if (!b || !d_planes) { set_error("kr_post_image: null argument"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : post_image_dev(spin, V, reverse, projradius, motion, lo, hi, b, d, n, d_planes, (hipStream_t) st);
 }
 int kr_imageplane_init_strided_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, void* d, int64_t count, void* st)
 {

@@ -272,15 +272,9 @@ pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_poin
 }
 
 // ---- ImagePlane ctor + init_image_plane (imageplane.cpp:11-121) ---------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny, long long first, long long stride)
+KR_DEV kr_ray_f64 imageplane_ray(const kr_imageplane& s, long long n_grid, int Ny, double a, double D, double incl, double phi0, long long ix)
 {
-    const long long n_grid = (long long) Nx * Ny;
-    const double a = -1 * s.spin;                       // imageplane.cpp:12
-    const double D = s.dist, incl = s.inc_deg * kPi / 180, phi0 = s.phi0;
-    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
-        const long long ix = first + slot * stride;
-        kr_ray_f64 ray;
+    kr_ray_f64 ray;
         memset(&ray, 0, sizeof(ray));
         ray.steps = -1;
         if (ix < n_grid) {
@@ -329,9 +323,40 @@ imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane
             ray.alpha = x;
             ray.beta = y;
         }
+    return ray;
+}
+
+__global__ void __launch_bounds__(kBlock)
+imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny, long long first, long long stride)
+{
+    const long long n_grid = (long long) Nx * Ny;
+    const double a = -1 * s.spin;                       // imageplane.cpp:12
+    const double D = s.dist, incl = s.inc_deg * kPi / 180, phi0 = s.phi0;
+    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock)
+        rays[slot] = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, first + slot * stride);
+}
+
+// ---- fused prologue of the image pipeline: ImagePlane ctor + redshift_start(V, reverse, projradius) in one pass; `spin` is the
+//      Raytracer member (the ImagePlane has negated it), as for kr_redshift_start_dev_f64 -----------------------------------
+__global__ void __launch_bounds__(kBlock)
+imageplane_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny, long long first, long long stride, double spin,
+                            double V, int reverse, int projradius)
+{
+    const long long n_grid = (long long) Nx * Ny;
+    const double a = -1 * s.spin;
+    const double D = s.dist, incl = s.inc_deg * kPi / 180, phi0 = s.phi0;
+    const double am = reverse ? -1 * spin : spin;
+    if (V == -1) {
+        const kr_ray_f64 r0 = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, first);
+        V = keplerian_V(am, r0.r, r0.theta, projradius != 0);
+    }
+    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
+        kr_ray_f64 ray = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, first + slot * stride);
+        ray.emit = emit_value(ray, spin, am, V, reverse);
         rays[slot] = ray;
     }
 }
+
 
 // ---- emissivity reducer (emissivity.cpp:96-126) -----------------------------------------------------------
 // d_hist layout: [count(nr) | flux(nr) | emis(nr) | sum_redshift(nr) | sum_time(nr) | disc_count(1)], doubles.
@@ -427,6 +452,29 @@ KR_DEV double powerlaw3(double r, double q1, double rb1, double q2, double rb2, 
 }
 
 // d_planes layout: [nrays | flux | r | phi | enshift | time | emis](npix each) + disc_count(1), doubles.
+// one ray's contribution to the seven image planes (imageplane_disc_image.cpp:122-161); returns 1 if it was counted
+KR_DEV unsigned image_accumulate(double* planes, long long npix, const kr_image_bins& b, int steps, double r, double theta, double phi, double t, double g,
+                                 double alpha, double beta)
+{
+    if (!(steps > 0)) return 0;
+    const double z = r * kr_cos(theta);
+    if (!(z < 1E-2 && r >= b.r_isco && r < b.r_disc && g > 0)) return 0;
+    int ix = (int) ((alpha - b.x0) / b.img_dx);
+    int iy = (int) ((beta - b.y0) / b.img_dy);
+    if (b.flip_image) iy = b.img_ny - iy - 1;
+    if (!(ix >= 0 && ix < b.img_nx && iy >= 0 && iy < b.img_ny)) return 0;
+    const long long px = (long long) ix * b.img_ny + iy;
+    const double e = powerlaw3(r, b.q1, b.rb1, b.q2, b.rb2, b.q3);
+    atomicAdd(&planes[px], 1.0);
+    atomicAdd(&planes[npix + px], e / kr_pow(g, 3.0));
+    atomicAdd(&planes[2 * npix + px], r);
+    atomicAdd(&planes[3 * npix + px], phi);
+    atomicAdd(&planes[4 * npix + px], 1. / g);
+    atomicAdd(&planes[5 * npix + px], t);
+    atomicAdd(&planes[6 * npix + px], e);
+    return 1;
+}
+
 // A ray lands in one pixel and the ray grid is about the pixel grid, so contention is low: global f64 atomics.
 __global__ void __launch_bounds__(kBlock)
 reduce_image_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_image_bins b, double* __restrict__ planes)
@@ -435,26 +483,31 @@ reduce_image_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_image_b
     unsigned long long hits = 0;
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
         const kr_ray_f64* ray = &rays[i];
-        if (!(ray->steps > 0)) continue;
-        const double r = ray->r, g = ray->redshift;
-        const double z = r * kr_cos(ray->theta);
-        if (z < 1E-2 && r >= b.r_isco && r < b.r_disc && g > 0) {
-            int ix = (int) ((ray->alpha - b.x0) / b.img_dx);
-            int iy = (int) ((ray->beta - b.y0) / b.img_dy);
-            if (b.flip_image) iy = b.img_ny - iy - 1;
-            if (ix >= 0 && ix < b.img_nx && iy >= 0 && iy < b.img_ny) {
-                const long long px = (long long) ix * b.img_ny + iy;
-                const double e = powerlaw3(r, b.q1, b.rb1, b.q2, b.rb2, b.q3);
-                atomicAdd(&planes[px], 1.0);
-                atomicAdd(&planes[npix + px], e / kr_pow(g, 3.0));
-                atomicAdd(&planes[2 * npix + px], r);
-                atomicAdd(&planes[3 * npix + px], ray->phi);
-                atomicAdd(&planes[4 * npix + px], 1. / g);
-                atomicAdd(&planes[5 * npix + px], ray->t);
-                atomicAdd(&planes[6 * npix + px], e);
-                ++hits;
-            }
-        }
+        hits += image_accumulate(planes, npix, b, ray->steps, ray->r, ray->theta, ray->phi, ray->t, ray->redshift, ray->alpha, ray->beta);
+    }
+    if (hits) atomicAdd(&planes[7 * npix], (double) hits);
+}
+
+// ---- fused epilogue of the image pipeline: redshift(V, reverse, projradius, motion) + range_phi + the seven planes in one pass
+//      (imageplane_disc_image.cpp:117-161) -----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+post_image_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double V, int reverse, int projradius, int motion, double lo, double hi,
+                  kr_image_bins b, double* __restrict__ planes)
+{
+    const long long npix = (long long) b.img_nx * b.img_ny;
+    unsigned long long hits = 0;
+    for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
+        kr_ray_f64* ray = &rays[i];
+        kr_ray_f64 v;
+        v.r = ray->r; v.theta = ray->theta; v.k = ray->k; v.h = ray->h; v.Q = ray->Q; v.rdot_sign = ray->rdot_sign; v.thetadot_sign = ray->thetadot_sign;
+        v.emit = ray->emit;
+        const int steps = ray->steps;
+        const double g = redshift_value(v, spin, V, reverse, projradius, motion);
+        ray->redshift = g;
+        const double phi = ray->phi;
+        const double wrapped = range_phi_value(phi, steps, lo, hi);
+        if (!(wrapped == phi) && wrapped == wrapped) ray->phi = wrapped;
+        hits += image_accumulate(planes, npix, b, steps, v.r, v.theta, wrapped, ray->t, g, ray->alpha, ray->beta);
     }
     if (hits) atomicAdd(&planes[7 * npix], (double) hits);
 }
@@ -609,6 +662,30 @@ int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t firs
     if (first == 0 && stride == 1 && n < total) { set_error("kr_imageplane_init: n smaller than kr_imageplane_count()"); return KR_EINVAL; }
     if (n <= 0) return KR_OK;
     hipLaunchKernelGGL(imageplane_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nx, ny, (long long) first, (long long) stride);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int imageplane_init_emit_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, double spin, double V, int reverse, int projradius,
+                             hipStream_t st)
+{
+    int32_t nx = 0, ny = 0;
+    kr_imageplane_count(s, &nx, &ny);
+    if (first < 0 || stride < 1) { set_error("kr_imageplane_init_emit: bad first/stride"); return KR_EINVAL; }
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(imageplane_init_emit_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nx, ny, (long long) first,
+                       (long long) stride, spin, V, reverse, projradius);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int post_image_dev(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_image_bins* b, void* d, int64_t n,
+                   void* d_planes, hipStream_t st)
+{
+    if (b->img_nx <= 0 || b->img_ny <= 0) { set_error("kr_post_image: image size must be positive"); return KR_EINVAL; }
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(post_image_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, V, reverse, projradius, motion, lo, hi, *b,
+                       (double*) d_planes);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }

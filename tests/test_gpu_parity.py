@@ -487,3 +487,51 @@ def test_fused_pipeline_ends_equal_the_separate_passes(krlib):
     assert h0[5 * bins.nr] > 1e5
     np.testing.assert_array_equal(h0[:bins.nr], h1[:bins.nr])
     np.testing.assert_allclose(h0, h1, rtol=1e-12)
+
+
+def test_fused_image_pipeline_ends_equal_the_separate_passes(krlib):
+    """kr_imageplane_init_emit_dev_f64 / kr_post_image_dev_f64 against the five separate image-pipeline passes."""
+    lib, vp = krlib, C.c_void_p
+    N = 301
+    spec = ol.imageplane_spec(10000.0, 80.0, -30.0, 30.0, 60.0 / N, -30.0, 30.0, 60.0 / N, gc.SPIN)
+    n = lib.kr_imageplane_count(C.byref(spec), None, None)
+    b = capi.ImageBins()
+    b.x0, b.y0, b.img_dx, b.img_dy = -30.0, -30.0, 60.0 / 64, 60.0 / 64
+    b.r_isco, b.r_disc = lib.kr_kerr_isco(gc.SPIN, 1), 30.0
+    b.q1, b.rb1, b.q2, b.rb2, b.q3 = 3.0, 4.0, 3.0, 10.0, 3.0
+    b.img_nx, b.img_ny, b.flip_image, b.pad = 64, 64, 1, 0
+    words = 7 * 64 * 64 + 1
+    p = capi.default_params(-gc.SPIN)
+    p.integrator, p.r_max = capi.RK4, 11000.0
+    res = []
+    for fused in (False, True):
+        d_rays, d_pl = vp(), vp()
+        capi.check(lib, lib.kr_malloc(C.byref(d_rays), n * 144), "malloc")
+        capi.check(lib, lib.kr_malloc(C.byref(d_pl), words * 8), "malloc")
+        capi.check(lib, lib.kr_memset(d_pl, 0, words * 8), "memset")
+        if fused:
+            capi.check(lib, lib.kr_imageplane_init_emit_dev_f64(C.byref(spec), 0, 1, 0.0, 1, 0, d_rays, n, None), "init_emit")
+        else:
+            capi.check(lib, lib.kr_imageplane_init_dev_f64(C.byref(spec), d_rays, n, None), "init")
+            capi.check(lib, lib.kr_redshift_start_dev_f64(-gc.SPIN, 0.0, 1, 0, d_rays, n, None), "redshift_start")
+        start = np.zeros(n, dtype=capi.RAY_F64)
+        capi.check(lib, lib.kr_memcpy_d2h(start.ctypes.data_as(vp), d_rays, n * 144), "d2h")
+        capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, None), "trace")
+        if fused:
+            capi.check(lib, lib.kr_post_image_dev_f64(-gc.SPIN, -1.0, 1, 0, 0, -np.pi, np.pi, C.byref(b), d_rays, n, d_pl, None), "post")
+        else:
+            capi.check(lib, lib.kr_redshift_dev_f64(-gc.SPIN, -1.0, 1, 0, 0, d_rays, n, None), "redshift")
+            capi.check(lib, lib.kr_range_phi_dev_f64(-np.pi, np.pi, d_rays, n, None), "range_phi")
+            capi.check(lib, lib.kr_reduce_image_dev_f64(C.byref(b), d_rays, n, d_pl, None), "reduce")
+        end = np.zeros(n, dtype=capi.RAY_F64)
+        planes = np.zeros(words)
+        capi.check(lib, lib.kr_memcpy_d2h(end.ctypes.data_as(vp), d_rays, n * 144), "d2h")
+        capi.check(lib, lib.kr_memcpy_d2h(planes.ctypes.data_as(vp), d_pl, words * 8), "d2h")
+        lib.kr_free(d_rays)
+        lib.kr_free(d_pl)
+        res.append((start, end, planes))
+    (s0, e0, p0), (s1, e1, p1) = res
+    assert ol.rays_equal_bitwise(s0, s1) == [] and ol.rays_equal_bitwise(e0, e1) == []
+    assert p0[-1] > 1000 and p0[-1] == p1[-1]
+    np.testing.assert_array_equal(p0[:64 * 64], p1[:64 * 64])
+    np.testing.assert_allclose(p0, p1, rtol=1e-12)
