@@ -279,7 +279,7 @@ class ReturnRadiationWorkload:
         self.result_words = 4 * self.nr
         self.describe = (f"disc->disc returning radiation: {self.nr} source radii r_isco..500 x ~{int(rays)} rays (beta in [0,pi)), {args.integrator.upper()}, "
                          f"r_max=1.1*r_esc, per-radius relaunch (BASELINE configs[4])")
-        self.pipeline = "per radius: pointsource_init+redshift_start+trace+range_phi+return_classification"
+        self.pipeline = "per radius: [pointsource_init+redshift_start]+trace+range_phi+return_classification"
         self.sharding = f"radii cyclic over {world} rank(s)"
 
     def step(self, d_rays, d_res, stream):
@@ -287,8 +287,7 @@ class ReturnRadiationWorkload:
         tot = None
         for (ir, r_s), s in zip(self.radii, self.specs):
             n = self.api.pointsource_count(s)[0]
-            capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(s), vp(d_rays), n, vp(stream)), "init")
-            capi.check(lib, lib.kr_redshift_start_dev_f64(SPIN, s.V, 0, 0, vp(d_rays), n, vp(stream)), "redshift_start")
+            capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(s), 0, 1, s.V, 0, 0, vp(d_rays), n, vp(stream)), "init+redshift_start (fused)")
             st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
             capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(d_rays), n, vp(stream)), "range_phi")
             b = capi.ReturnBins()
