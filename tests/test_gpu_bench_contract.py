@@ -32,6 +32,7 @@ def test_bench_line_and_kernel_overlap_under_rccl():
     assert d["config"]["rays_on_strict_side_launch"] == 3162
     # value is what the timed region did: rays * steps / wall
     assert abs(d["value"] - d["config"]["rays_total"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-    # concurrency: the hybrid pass must be clearly shorter than the all-strict pass (166 ms); serialised it is ~200 ms
-    strict_ms = d["other_arithmetic_modes"]["strict"]["avg_kernel_ms"]
-    assert roof["avg_kernel_ms"] < 0.8 * strict_ms, (roof["avg_kernel_ms"], strict_ms)
+    # concurrency: overlapped, the hybrid pass takes max(side launch ~100 ms, fast launch ~90 ms) = ~1.2 x the all-fast pass (85 ms);
+    # serialised it would be their sum, ~2.2 x
+    fast_ms = d["other_arithmetic_modes"]["fast"]["avg_kernel_ms"]
+    assert roof["avg_kernel_ms"] < 1.6 * fast_ms, (roof["avg_kernel_ms"], fast_ms)
