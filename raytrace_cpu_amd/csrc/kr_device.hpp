@@ -70,7 +70,9 @@ KR_DEV double div_by_uniform(double a, double b, double inv_b, bool ok)
 
 KR_DEV double lean_sqrt(double x)      // x >= 0; +0 -> +0
 {
-    const double y = __builtin_amdgcn_rsq(x);
+    // rsq(0) = inf would turn the chain into NaN; capped at 1e300 (a no-op for every x > 0, whose rsq is < 1e154) the chain
+    // returns +0 for +0 by itself: one v_min instead of a compare and two selects on the result
+    const double y = __builtin_fmin(__builtin_amdgcn_rsq(x), 1e300);
     const double g0 = x * y;
     const double h0 = y * 0.5;
     const double r0 = __builtin_fma(-h0, g0, 0.5);
@@ -79,8 +81,7 @@ KR_DEV double lean_sqrt(double x)      // x >= 0; +0 -> +0
     const double d0 = __builtin_fma(-g1, g1, x);
     const double g2 = __builtin_fma(d0, h1, g1);
     const double d1 = __builtin_fma(-g2, g2, x);
-    const double g3 = __builtin_fma(d1, h1, g2);
-    return (x == 0.0) ? x : g3;
+    return __builtin_fma(d1, h1, g2);
 }
 
 // arithmetic policy of the strict path: LEAN (double, KR_LEAN_IEEE) or the compiler's sequences
