@@ -30,6 +30,8 @@ for c in caustic_discplane caustic_discplane_rk45 caustic_sourceplane; do
 done
 # BASELINE configs[2]: one point (tol = 1e-8) of the RK45 tolerance sweep, src/tests/emissivity_rk45_plot.cpp
 $APPS/emissivity_rk45_plot $G/emissivity_rk45_plot.csv 1e-8 > /dev/null
+# src/tests/integrator_perf_test.cpp: the step statistics of its report (timing lines left out)
+$APPS/integrator_perf_test | grep -E "^(Total rays|Valid rays|Invalid rays|Steps per ray|Total steps|Total func)" > $G/integrator_perf_test.txt
 $APPS/raytrace_rk4_test    | tail -16 > $G/raytrace_rk4_test.txt
 $APPS/emissivity_rk45_test | tail -40 > $G/emissivity_rk45_test.txt
 ls -la $G

@@ -126,6 +126,28 @@ def test_rk45_tolerance_sweep_program_matches_cpu_output():
         np.testing.assert_allclose(got[same, col], want[same, col], rtol=rtol, err_msg=f"column {col}")
 
 
+def test_integrator_perf_report_matches_cpu_statistics():
+    """src/tests/integrator_perf_test.cpp on the HIP path: the per-ray step statistics of its report (ray counts, min / mean /
+    median / percentiles / max, totals for RK4 and RK45) against the CPU build's.  RK4 columns equal; RK45 within the +-1 step per
+    ray that its adaptive step control turns libm differences into."""
+    exe = need("integrator_perf_test")
+    r = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=600)
+    assert r.returncode == 0, r.stderr[-1000:]
+    def table(text):
+        rows = {}
+        for l in text.splitlines():
+            if l.startswith(("Total rays", "Valid rays", "Invalid rays", "Steps per ray", "Total steps", "Total func")):
+                parts = l.split()
+                rows[" ".join(parts[:-2])] = (float(parts[-2]), float(parts[-1]))
+        return rows
+    got, want = table(r.stdout), table(open(os.path.join(APPS, "integrator_perf_test.txt")).read())
+    assert set(got) == set(want) and len(want) == 11
+    for key, (w4, w45) in want.items():
+        g4, g45 = got[key]
+        assert g4 == w4, (key, g4, w4)                                     # RK4: identical
+        assert abs(g45 - w45) <= max(2.0, 2e-3 * abs(w45)), (key, g45, w45)
+
+
 def test_reference_self_tests_pass_on_the_hip_path():
     """src/tests/raytrace_rk4_test.cpp and emissivity_rk45_test.cpp, built against the HIP path, still PASS and
     report the same classification counts as their CPU runs."""
