@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 6
+#define KR_ABI_VERSION 7
 
 /* error codes */
 #define KR_OK          0
@@ -79,7 +79,8 @@ extern "C" {
                                            Ignored by the f32 entry points and when KR_FLAG_FAST_MATH is set. */
 #define KR_FLAG_RK45_ITERATE_ALL (1 << 2) /* RK45: iterate creeping captured rays to the step limit one step at a time, as the reference does,
                                            instead of extrapolating them (kr_stats.rk45_extrapolated_steps) */
-#define KR_FLAG_BLOCKS_PER_CU(n)      (((n) & 0xF) << 8)   /* resident 256-thread workgroups per CU for the trace kernel, 0 = default (2) */
+#define KR_FLAG_BLOCKS_PER_CU(n)      (((n) & 0xF) << 8)   /* resident 256-thread workgroups per CU for the trace kernel; 0 = default: 3 for the main
+                                                              launch of a split trace, for n >= 2e7 and for fast-math with n >= 5e6, else 2 */
 #define KR_FLAG_GET_BLOCKS_PER_CU(f)  (((f) >> 8) & 0xF)
 
 /* defaults, raytracer.h:19-44 */
@@ -147,6 +148,8 @@ typedef struct kr_stats {
     int64_t rk45_extrapolated_steps; /* RK45: steps (included in steps_total and rk45_attempts) of captured rays whose r was stationary
                                        and whose theta advanced by a constant number of ulps per step: extrapolated to the step
                                        limit (r, theta, every integer output exact; t, phi, momenta to ~1e-11) */
+    double  strict_side_ms;         /* split traces: duration of the strict side launch (caller's stream) ... */
+    double  main_ms;                /* ... and of the main launch beside it (internal stream); kernel_ms spans both.  0 otherwise */
 } kr_stats;
 
 /* PointSource<T> ctor arguments (pointsource.h:24, pointsource.cpp:11-64) */
@@ -217,14 +220,22 @@ int64_t     kr_imageplane_count(const kr_imageplane* s, int32_t* nx, int32_t* ny
 /* ---- the hot path: Raytracer<T>::run_raytrace, both overloads (raytracer.cpp:63-127, 972-1034) --
  * Host-pointer forms stage through a private device buffer and return when rays[] is final.  *_dev forms take a device
  * pointer and a hipStream_t (NULL: the default stream): work is enqueued on that stream and, with stats == NULL, the call
- * returns before it has finished -- except that a split launch (KR_FLAG_HYBRID, or flags = 0 with >= 2^18 rays) first
- * synchronises the stream once to read the size of its side launch.  Per device the library keeps one set of queue counters,
- * index lists and events: trace calls for one device must not overlap in time (one caller thread, one stream at a time);
- * the reference's caller is single-threaded too. */
+ * returns before it has finished; nothing in the launch path waits for the device.  Every call draws its queue counters,
+ * index list, events and second stream from a per-device pool of workspaces and gives them back when its last kernel
+ * has finished, so any number of traces may be in flight on one device, from several streams or host threads
+ * (multi-launch drivers -- one launch per source radius, one per tolerance -- overlap their long-ray tails that way). */
 int kr_trace_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, kr_stats* stats);
 int kr_trace_f32(const kr_params* p, kr_ray_f32* rays, int64_t n, kr_stats* stats);
 int kr_trace_dev_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, kr_stats* stats);
 int kr_trace_dev_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, kr_stats* stats);
+/* The same trace in two halves, for callers that want the counters of overlapping launches: kr_trace_async_* enqueues and
+ * returns a ticket at once; kr_trace_wait blocks until THAT trace has finished, fills *stats (may be NULL) and retires the
+ * ticket; kr_trace_release retires it without waiting.  Every ticket must go to exactly one of the two (at most 64 may be
+ * outstanding per device).  kr_trace_dev_*(.., stats) == async + wait;  (.., NULL) == async + release. */
+int kr_trace_async_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, void** ticket);
+int kr_trace_async_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, void** ticket);
+int kr_trace_wait(void* ticket, kr_stats* stats);
+int kr_trace_release(void* ticket);
 
 /* ---- O(N) passes either side of it ----------------------------------------------------------- */
 /* Raytracer<T>::redshift_start(V, reverse, projradius)  raytracer.cpp:342-417 */
@@ -310,6 +321,10 @@ int kr_memcpy_h2d(void* d_dst, const void* h_src, int64_t bytes);
 int kr_memcpy_d2h(void* h_dst, const void* d_src, int64_t bytes);
 int kr_memset(void* d_ptr, int value, int64_t bytes);
 int kr_synchronize(void* stream);
+/* streams for such callers (hipStreamCreateWithFlags(hipStreamNonBlocking) / hipStreamDestroy); the handle is what the *_dev
+ * entry points take as `stream` */
+int kr_stream_create(void** stream);
+int kr_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,24 @@ def trace_dev(params, d_ptr, n, stream=None, want_stats=True, f32=False):
     return st.as_dict() if st else None
 
 
+def trace_async(params, d_ptr, n, stream=None, f32=False):
+    """kr_trace_async_*: enqueues the trace on `stream`, returns a ticket for trace_wait / trace_release."""
+    ticket = C.c_void_p()
+    fn = lib().kr_trace_async_f32 if f32 else lib().kr_trace_async_f64
+    capi.check(lib(), fn(C.byref(params), C.c_void_p(d_ptr), n, C.c_void_p(stream or 0), C.byref(ticket)), "kr_trace_async")
+    return ticket
+
+
+def trace_wait(ticket, want_stats=True):
+    st = Stats() if want_stats else None
+    capi.check(lib(), lib().kr_trace_wait(ticket, C.byref(st) if st else None), "kr_trace_wait")
+    return st.as_dict() if st else None
+
+
+def trace_release(ticket):
+    capi.check(lib(), lib().kr_trace_release(ticket), "kr_trace_release")
+
+
 def redshift_start(spin, V, reverse, projradius, rays):
     _rays_arg(rays, capi.RAY_F64)
     capi.check(lib(), lib().kr_redshift_start_f64(spin, V, int(reverse), int(projradius), _ptr(rays), len(rays)), "kr_redshift_start")

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -38,7 +38,8 @@ class Params(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("rays_total", "rays_traced", "steps_total", "rk45_attempts", "rk45_rejects")] + \
-               [(n, C.c_double) for n in ("kernel_ms", "h2d_ms", "d2h_ms")] + [("rays_strict_side", C.c_int64), ("rk45_stationary_steps", C.c_int64), ("rk45_extrapolated_steps", C.c_int64)]
+               [(n, C.c_double) for n in ("kernel_ms", "h2d_ms", "d2h_ms")] + [("rays_strict_side", C.c_int64), ("rk45_stationary_steps", C.c_int64), ("rk45_extrapolated_steps", C.c_int64)] + \
+               [("strict_side_ms", C.c_double), ("main_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -115,6 +116,10 @@ PROTOTYPES = {
     "kr_trace_f32": (_int, [P(Params), _vp, _i64, P(Stats)]),
     "kr_trace_dev_f64": (_int, [P(Params), _vp, _i64, _vp, P(Stats)]),
     "kr_trace_dev_f32": (_int, [P(Params), _vp, _i64, _vp, P(Stats)]),
+    "kr_trace_async_f64": (_int, [P(Params), _vp, _i64, _vp, P(_vp)]),
+    "kr_trace_async_f32": (_int, [P(Params), _vp, _i64, _vp, P(_vp)]),
+    "kr_trace_wait": (_int, [_vp, P(Stats)]),
+    "kr_trace_release": (_int, [_vp]),
     "kr_redshift_start_f64": (_int, [_dbl, _dbl, _int, _int, _vp, _i64]),
     "kr_redshift_start_dev_f64": (_int, [_dbl, _dbl, _int, _int, _vp, _i64, _vp]),
     "kr_redshift_f64": (_int, [_dbl, _dbl, _int, _int, _int, _vp, _i64]),
@@ -150,6 +155,8 @@ PROTOTYPES = {
     "kr_memcpy_d2h": (_int, [_vp, _vp, _i64]),
     "kr_memset": (_int, [_vp, _int, _i64]),
     "kr_synchronize": (_int, [_vp]),
+    "kr_stream_create": (_int, [P(_vp)]),
+    "kr_stream_destroy": (_int, [_vp]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libkrtrace.so")

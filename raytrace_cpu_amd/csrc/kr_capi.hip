@@ -206,6 +206,26 @@ int kr_trace_dev_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, 
     return trace_dev(p, d_rays, n, (hipStream_t) stream, stats, true);
 }
 
+int kr_trace_async_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, void** ticket)
+{
+    if (!ticket) { set_error("kr_trace_async: null ticket pointer"); return KR_EINVAL; }
+    return trace_async(p, d_rays, n, (hipStream_t) stream, false, ticket);
+}
+
+int kr_trace_async_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, void** ticket)
+{
+    if (!ticket) { set_error("kr_trace_async: null ticket pointer"); return KR_EINVAL; }
+    return trace_async(p, d_rays, n, (hipStream_t) stream, true, ticket);
+}
+
+int kr_trace_wait(void* ticket, kr_stats* stats) { return trace_wait(ticket, stats); }
+
+int kr_trace_release(void* ticket)
+{
+    trace_release(ticket);
+    return KR_OK;
+}
+
 int kr_trace_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, kr_stats* stats)
 {
     if (!p) { set_error("kr_trace: null params"); return KR_EINVAL; }
@@ -508,6 +528,21 @@ int kr_memset(void* d_ptr, int value, int64_t bytes)
 int kr_synchronize(void* stream)
 {
     KR_HIP(hipStreamSynchronize((hipStream_t) stream));
+    return KR_OK;
+}
+int kr_stream_create(void** stream)
+{
+    if (!stream) { set_error("kr_stream_create: null argument"); return KR_EINVAL; }
+    int rc = require_device();
+    if (rc != KR_OK) return rc;
+    hipStream_t s = nullptr;
+    KR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*) s;
+    return KR_OK;
+}
+int kr_stream_destroy(void* stream)
+{
+    if (stream) KR_HIP(hipStreamDestroy((hipStream_t) stream));
     return KR_OK;
 }
 

@@ -22,7 +22,56 @@
 //   correction (Sun fdlibm k_sin.c / k_cos.c coefficients; < 1 ulp); quadrant fix-up by n mod 4.
 // About 45 instructions for both results.  |x| >= 1024 (never reached by a healthy ray) and non-finite inputs
 // take the library path.
+//
+// Small polar angles (|x| < 2^-7) take a branch of their own, kr_sincos_small_f64: no reduction (n = 0, r = x exactly), no
+// quadrant logic, Taylor kernels x + x z (S1 + z (S2 + z S3)) and 1 + (z^2 (C2 + z C3) - z/2) with z = x^2 < 6.2e-5: the first
+// dropped terms are 3.8e-23 x and 3.4e-22, every intermediate rounding is scaled by <= z, so both results are within
+// 0.5001 ulp (tests/test_sincos_accuracy.py).  10 fp64 instructions instead of ~34 fp64 + ~22 integer / select ones.  Why it
+// matters: rays that ride the polar axis (the beta = -pi column of a lamp-post PointSource: theta stays at the source's 1e-3
+// for 3e4 steps, 1e5 under RK45) are the longest rays of a launch, and a launch cannot end before its longest ray does.
+// The choice is a pure function of x, so a ray gets the same bits in whichever kernel / wave it is traced; on the device the
+// branch is taken wave-uniformly (all lanes small -> only the short kernel; mixed wave -> both and a select).
+#ifndef KR_SMALL_ANGLE_SINCOS
+#define KR_SMALL_ANGLE_SINCOS 1
+#endif
+#define KR_SMALL_ANGLE_LIMIT 0.0078125      /* 2^-7 */
+KR_SC_FN void kr_sincos_small_f64(double x, double& s, double& c)
+{
+    const double z = x * x;
+    const double ps = __builtin_fma(z, __builtin_fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01);
+    s = __builtin_fma(x * z, ps, x);
+    const double pc = __builtin_fma(z, -1.38888888888888888889e-03, 4.16666666666666666667e-02);
+    c = 1.0 + __builtin_fma(z * z, pc, -0.5 * z);
+}
+
+KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c);
+
 KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
+{
+#if KR_SMALL_ANGLE_SINCOS && KR_COMPACT_SINCOS
+    const bool small = __builtin_fabs(x) < KR_SMALL_ANGLE_LIMIT;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(!small) == 0) {      // every active lane: the usual case on a wave of polar-axis rays
+        kr_sincos_small_f64(x, s, c);
+        return;
+    }
+    kr_sincos_general_f64(x, s, c);
+    if (__builtin_amdgcn_ballot_w64(small) != 0) {       // mixed wave
+        double s1, c1;
+        kr_sincos_small_f64(x, s1, c1);
+        s = small ? s1 : s;
+        c = small ? c1 : c;
+    }
+#else
+    if (small) kr_sincos_small_f64(x, s, c);
+    else kr_sincos_general_f64(x, s, c);
+#endif
+#else
+    kr_sincos_general_f64(x, s, c);
+#endif
+}
+
+KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
 {
 #if KR_COMPACT_SINCOS
     const double ax = __builtin_fabs(x);

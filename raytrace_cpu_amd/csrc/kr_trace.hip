@@ -28,6 +28,7 @@
 #include <cstring>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "kr_common.hpp"
 #include "kr_device.hpp"
@@ -50,6 +51,8 @@ constexpr int kBlock = 256;          // 4 independent waves per workgroup, no ba
 #define KR_LONG_RAY_STEPS 2048
 #endif
 constexpr int kCounters = 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps, [6] rk45 extrapolated steps
+constexpr int kCounterBlocks = 4;    // main launch, strict side launch, strict overflow launch, split bookkeeping ([1] = number of ill-conditioned rays)
+constexpr int kListCap = 32768;      // index-list entries of the strict side launch (= 128 workgroups x 256 lanes, half of the chip)
 
 template <typename T> struct RayOf;
 template <> struct RayOf<double> { using type = kr_ray_f64; };
@@ -109,9 +112,9 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 // ---- the persistent kernel ------------------------------------------------------------------------
 // METHOD: KR_EULER / KR_RK4 / KR_RK45.  REFILL_MIN: a wave goes back to the queue when at least this many of its
 // lanes are free (or when none holds a ray).
-// `list` (optional): the launch works on rays list[0 .. n) instead of rays 0 .. n); `n_ptr` (optional): n is read from
-// device memory (the classification kernel of the hybrid path produced it); `skip` (optional): rays with skip[i] != 0
-// are left alone (they belong to the other launch of the hybrid path).  HOG: the kernel claims the whole register
+// `list` (optional): the launch works on rays list[0 .. n) instead of rays 0 .. n); `n_ptr` (optional): the item count is read
+// from device memory (the classification kernel of the split path produced it; see n_mode below); `mask` (optional): only
+// rays with mask[i] == mask_want are traced (the others belong to another launch of the split).  HOG: the kernel claims the whole register
 // file (512 VGPR+AGPR per lane), so each of its waves owns its SIMD and no other kernel's wave can be co-resident on
 // the CUs it occupies -- used for the few ill-conditioned / long rays that define the critical path.
 #ifndef KR_HOG_ATTR
@@ -124,10 +127,15 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
 __global__ void __attribute__((amdgpu_flat_work_group_size(kBlock, kBlock))) KR_HOG_ATTR
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
-             const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, const unsigned char* __restrict__ skip)
+             const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want)
 {
     if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
-    if (n_ptr) n = (long long) *n_ptr;
+    if (n_ptr) {
+        // the item count was produced on the device (classify_kernel) and never visits the host:
+        // n_mode 1: the first min(n, *n_ptr) list entries;  n_mode 2: all n slots, but only if the list overflowed (else nothing)
+        const long long m = (long long) *n_ptr;
+        n = (n_mode == 1) ? (m < n ? m : n) : (m > (long long) kListCap ? n : 0);
+    }
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_bit = 1ull << lane;
 
@@ -155,7 +163,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
             if (base + (unsigned long long) n_need >= (unsigned long long) n) exhausted = true;
             if (!have) {
                 const long long slot = (long long) base + __popcll(need & (lane_bit - 1));
-                if (slot < n && !(skip && skip[slot])) {
+                if (slot < n && !(mask && mask[slot] != (unsigned char) mask_want)) {
                     const long long mine = list ? (long long) list[slot] : slot;
                     load_ray(&rays[mine], s);
                     // skip rule of run_raytrace (raytracer.cpp:116-117)
@@ -275,59 +283,129 @@ classify_kernel(const kr_ray_f64* __restrict__ rays, long long n, double a, unsi
         const double sum = Q + prod;
         strict = !(__builtin_fabs(sum) > 1e-9 * (__builtin_fabs(Q) + __builtin_fabs(prod))) || !(__builtin_fabs(h) >= 1e-13);
     }
-    strict_mask[i] = strict ? 1 : 0;
-    // wave-aggregated append; ill-conditioned rays are rare (a column / a row of the source grid), so are the atomics
+    // wave-aggregated append; ill-conditioned rays are rare (a column / a row of the source grid), so are the atomics.
+    // mask: 0 = main launch, 1 = listed (strict side launch), 2 = ill-conditioned but the list is full (strict overflow launch)
     const unsigned long long m = __ballot(strict);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long) m) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(n_strict, (unsigned long long) __popcll(m));
-    base = __shfl(base, leader, 64);
-    if (strict) list_strict[base + __popcll(m & ((1ull << lane) - 1))] = (int) i;
+    unsigned char mine = 0;
+    if (m != 0) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long) m) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(n_strict, (unsigned long long) __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (strict) {
+            const unsigned long long slot = base + __popcll(m & ((1ull << lane) - 1));
+            if (slot < (unsigned long long) kListCap) { list_strict[slot] = (int) i; mine = 1; }
+            else mine = 2;
+        }
+    }
+    strict_mask[i] = mine;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
-struct DeviceScratch {
-    unsigned long long* counters = nullptr;      // 3 blocks of kCounters: main launch, side launch, {n_fast, n_strict}
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_classified = nullptr, ev_side_done = nullptr;
-    hipStream_t side_stream = nullptr;
-    int* lists = nullptr;                        // hybrid path: capacity ray indices (strict list) + capacity mask bytes
-    int64_t list_capacity = 0;
+// Everything one trace call needs besides the rays -- queue heads and counters, the strict list and mask, timing events, the
+// second stream of a split launch -- lives in a Workspace taken from a per-device pool for the duration of the call
+// (until the call's last kernel has finished, which the pool learns from an event, not from the host).  Two traces on two
+// streams, or from two host threads, therefore never share mutable state: any number may be in flight on one device.
+struct Workspace {
+    int device = 0;
     int cus = 0;
+    unsigned long long* counters = nullptr;      // device: kCounterBlocks x kCounters
+    unsigned long long* h_counters = nullptr;    // pinned host copy, filled by an async copy at the end of the call
+    int* list = nullptr;                         // device: kListCap ray indices
+    unsigned char* mask = nullptr;               // device: one byte per ray
+    int64_t mask_capacity = 0;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;             // the whole trace, caller's stream
+    hipEvent_t ev_strict0 = nullptr, ev_strict1 = nullptr; // strict side (+ overflow) launch, caller's stream
+    hipEvent_t ev_main0 = nullptr, ev_main1 = nullptr;     // main launch of a split, side stream
+    hipEvent_t ev_classified = nullptr, done = nullptr;
+    bool leased = false;       // a caller holds it (between trace_async and trace_wait / trace_release)
+    bool pending = false;      // `done` has been recorded and not yet seen complete
+    bool split = false;        // the last call used the split path (ev_strict*/ev_main* are valid)
+    int64_t n = 0;
 };
-std::mutex g_mu;
-DeviceScratch g_scratch[64];
 
-int scratch_for_current(DeviceScratch** out)
+std::mutex g_mu;
+std::vector<Workspace*> g_pool[64];
+constexpr size_t kMaxPool = 64;
+
+int workspace_create(int dev, Workspace** out)
+{
+    Workspace* w = new Workspace();
+    w->device = dev;
+    auto fail = [&](int rc) { delete w; return rc; };       // (a half-built workspace leaks its few handles: only on a failing device)
+#define KR_WS(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(kr::hip_fail(e__, #call, __FILE__, __LINE__)); } while (0)
+    KR_WS(hipMalloc((void**) &w->counters, kCounterBlocks * kCounters * sizeof(unsigned long long)));
+    KR_WS(hipHostMalloc((void**) &w->h_counters, kCounterBlocks * kCounters * sizeof(unsigned long long), hipHostMallocDefault));
+    KR_WS(hipMalloc((void**) &w->list, kListCap * sizeof(int)));
+    KR_WS(hipEventCreate(&w->ev0));
+    KR_WS(hipEventCreate(&w->ev1));
+    KR_WS(hipEventCreate(&w->ev_strict0));
+    KR_WS(hipEventCreate(&w->ev_strict1));
+    KR_WS(hipEventCreate(&w->ev_main0));
+    KR_WS(hipEventCreate(&w->ev_main1));
+    KR_WS(hipEventCreateWithFlags(&w->ev_classified, hipEventDisableTiming));
+    KR_WS(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
+    {
+        // The side stream must not share a hardware queue with the caller's stream, or the two launches of a split
+        // serialise (seen once a process also holds RCCL's streams: HIP multiplexes streams onto a few queues per priority
+        // level).  A different priority level has queues of its own; the main launch it carries is also the one that may wait.
+        int least = 0, greatest = 0;
+        KR_WS(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        int prio = least;
+        if (const char* e = getenv("KR_SIDE_STREAM_PRIORITY")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "default") ? 0 : least;
+        KR_WS(hipStreamCreateWithPriority(&w->side_stream, hipStreamNonBlocking, prio));
+    }
+    hipDeviceProp_t prop;
+    KR_WS(hipGetDeviceProperties(&prop, dev));
+#undef KR_WS
+    w->cus = prop.multiProcessorCount;
+    *out = w;
+    return KR_OK;
+}
+
+// takes an idle workspace of the current device out of the pool (or makes one); the caller owns it until workspace_release
+int workspace_acquire(Workspace** out)
 {
     int dev = 0;
     KR_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) { set_error("device ordinal out of range"); return KR_EINVAL; }
-    std::lock_guard<std::mutex> lk(g_mu);
-    DeviceScratch& sc = g_scratch[dev];
-    if (!sc.counters) {
-        KR_HIP(hipMalloc((void**) &sc.counters, 3 * kCounters * sizeof(unsigned long long)));
-        KR_HIP(hipEventCreate(&sc.ev0));
-        KR_HIP(hipEventCreate(&sc.ev1));
-        KR_HIP(hipEventCreateWithFlags(&sc.ev_classified, hipEventDisableTiming));
-        KR_HIP(hipEventCreateWithFlags(&sc.ev_side_done, hipEventDisableTiming));
-        {
-            // The side stream must not share a hardware queue with the caller's stream, or the two launches of the hybrid path
-            // serialise (seen once a process also holds RCCL's streams: HIP multiplexes streams onto a few queues per priority
-            // level).  A different priority level has queues of its own; the fast launch it carries is also the one that may wait.
-            int least = 0, greatest = 0;
-            KR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            int prio = least;
-            if (const char* e = getenv("KR_SIDE_STREAM_PRIORITY")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "default") ? 0 : least;
-            KR_HIP(hipStreamCreateWithPriority(&sc.side_stream, hipStreamNonBlocking, prio));
+    Workspace* wait_for = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (Workspace* w : g_pool[dev]) {
+            if (w->leased) continue;
+            if (w->pending) {
+                if (hipEventQuery(w->done) != hipSuccess) { (void) hipGetLastError(); if (!wait_for) wait_for = w; continue; }
+                w->pending = false;
+            }
+            w->leased = true;
+            *out = w;
+            return KR_OK;
         }
-        hipDeviceProp_t prop;
-        KR_HIP(hipGetDeviceProperties(&prop, dev));
-        sc.cus = prop.multiProcessorCount;
+        if (g_pool[dev].size() < kMaxPool) {
+            Workspace* w = nullptr;
+            const int rc = workspace_create(dev, &w);
+            if (rc != KR_OK) return rc;
+            w->leased = true;
+            g_pool[dev].push_back(w);
+            *out = w;
+            return KR_OK;
+        }
+        if (!wait_for) { set_error("kr_trace: too many trace tickets outstanding on this device (kr_trace_wait releases them)"); return KR_EINVAL; }
+        wait_for->leased = true;          // ours from here on; its last call is still running
     }
-    *out = &sc;
+    KR_HIP(hipEventSynchronize(wait_for->done));
+    wait_for->pending = false;
+    *out = wait_for;
     return KR_OK;
+}
+
+void workspace_release(Workspace* w)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    w->leased = false;
 }
 
 template <typename T>
@@ -362,7 +440,9 @@ constexpr int64_t kIsolateMinRays = 1 << 18;      // below this a strict launch 
 struct ListArgs {
     const int* list = nullptr;                    // ray indices, or null for 0 .. n
     const unsigned long long* n_ptr = nullptr;    // item count in device memory, or null (use n)
-    const unsigned char* skip = nullptr;          // per-ray "not mine" mask, or null
+    int n_mode = 0;                               // how n_ptr is applied (trace_kernel)
+    const unsigned char* mask = nullptr;          // per-ray launch selector, or null
+    int mask_want = 0;
     int fixed_grid = 0;                           // > 0: launch exactly this many workgroups
 };
 
@@ -372,9 +452,14 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
 {
     constexpr int kRefill = KR_REFILL_MIN;
     auto kern = trace_kernel<T, METHOD, USE_DEST, FAST, HOG, kRefill>;
-    int blocks_per_cu = 0;
-    KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kern, kBlock, 0));
-    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    // occupancy of each instance is a property of the code object: asked once per process
+    static int occ = 0;
+    if (occ == 0) {
+        int v = 0;
+        KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, kBlock, 0));
+        occ = v < 1 ? 1 : v;
+    }
+    int blocks_per_cu = occ;
     // Resident workgroups per CU (= waves per SIMD).  The launch ends with its longest ray, which advances one step
     // per turn of its wave: with w waves per SIMD that turn comes round ~w times slower, while throughput keeps
     // improving up to ~3 waves.  Measured on MI355X, RK4 f64 strict, kernel ms at 1 / 2 / 3 workgroups per CU:
@@ -392,7 +477,7 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     const int64_t wanted = (n + kBlock - 1) / kBlock;
     int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
     if (la.fixed_grid > 0) grid = la.fixed_grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.skip);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.n_mode, la.mask, la.mask_want);
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
@@ -414,59 +499,66 @@ int launch_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, const TraceConst
     }
 }
 
-// classify -> strict HOG launch over the ill-conditioned rays (caller's stream)  ||  main launch over the rest (side stream).
+// The split trace: classify -> strict HOG launch over the (listed) ill-conditioned rays, on the caller's stream, first, so that
+// its workgroups are placed while the chip is still empty  ||  main launch over all other rays on the workspace's side
+// stream, filling what is left (the other way round the main launch takes every SIMD's registers and the strict one waits).
 // fast_main: the main launch uses the fast arithmetic (KR_FLAG_HYBRID); otherwise it is the strict kernel too, i.e. the
 // results are those of one strict launch, bit for bit, and only the placement of the long rays differs.
-int dispatch_split(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, DeviceScratch* sc, hipStream_t stream, bool fast_main)
+// Nothing here waits for the device: how many rays were flagged stays in device memory (counters block 3, word 1) and the
+// launches read it there.  The side launch is sized for the worst case the list can hold (workgroups that find the queue
+// empty leave at once); a source made mostly of ill-conditioned rays (all rays in one meridional plane, say) overflows the
+// list, and the overflow -- mask value 2 -- is traced by a third, ordinary-occupancy strict launch that is a no-op otherwise.
+int dispatch_split(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream, bool fast_main)
 {
-    if (n > 0x7fffffff) { set_error("kr_trace: hybrid path indexes rays with 32 bits"); return KR_EINVAL; }
-    if (sc->list_capacity < n) {
-        if (sc->lists) KR_HIP(hipFree(sc->lists));
-        sc->lists = nullptr;
-        sc->list_capacity = 0;
-        KR_HIP(hipMalloc((void**) &sc->lists, (size_t) n * (sizeof(int) + 1)));
-        sc->list_capacity = n;
+    if (n > 0x7fffffff) { set_error("kr_trace: the split path indexes rays with 32 bits"); return KR_EINVAL; }
+    if (ws->mask_capacity < n) {
+        // (the workspace is idle: its previous call has completed, or it would not have been handed out)
+        if (ws->mask) KR_HIP(hipFree(ws->mask));
+        ws->mask = nullptr;
+        ws->mask_capacity = 0;
+        KR_HIP(hipMalloc((void**) &ws->mask, (size_t) n));
+        ws->mask_capacity = n;
     }
-    int* list_strict = sc->lists;
-    unsigned char* strict_mask = (unsigned char*) (sc->lists + n);
-    unsigned long long* counts = sc->counters + 2 * kCounters;     // [1] n_strict (zeroed by the caller's memset)
+    unsigned long long* split_words = ws->counters + 3 * kCounters;     // [1] n_strict (zeroed by the caller's memset)
     const TraceConsts<double> c = make_consts<double>(p, steplim);
     const int mb = KR_FLAG_GET_BLOCKS_PER_CU(p->flags);
     const int cgrid = (int) ((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, strict_mask, list_strict, counts + 1);
+    hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, ws->mask, ws->list, split_words + 1);
     KR_HIP(hipGetLastError());
-    // The split decides the launch geometry, so the host has to see it: one 8-byte read-back (~30 us against a >= 1 ms trace).
-    unsigned long long n_strict = 0;
-    KR_HIP(hipMemcpyAsync(&n_strict, counts + 1, sizeof(n_strict), hipMemcpyDeviceToHost, stream));
-    KR_HIP(hipStreamSynchronize(stream));
-    if (n_strict == 0)
-        return fast_main ? launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, stream, mb, ListArgs())
-                         : launch_f64<false, false>(p, rays, n, c, sc->counters, sc->cus, stream, mb, ListArgs());
-    if (n_strict > (unsigned long long) n / 8) {
-        // a source made mostly of ill-conditioned rays (e.g. all rays in one meridional plane): exclusive SIMDs for a few
-        // rays is the wrong shape -- everything goes through the strict kernel at its normal occupancy
-        const int rc = launch_f64<false, false>(p, rays, n, c, sc->counters, sc->cus, stream, mb, ListArgs());
-        return rc;
-    }
-    KR_HIP(hipEventRecord(sc->ev_classified, stream));
-    // The strict launch goes FIRST and on the caller's stream (right behind the classification, no cross-queue latency), so its
-    // workgroups are placed while the chip is still empty; the fast launch arrives through the event on the side stream and
-    // fills what is left.  (The other way round the fast launch takes every SIMD's registers and the strict one waits for it.)
-    // One workgroup (4 waves, each alone on its SIMD) per 256 strict rays, on at most half of the CUs.
+    KR_HIP(hipEventRecord(ws->ev_classified, stream));
+    KR_HIP(hipEventRecord(ws->ev_strict0, stream));
+    // strict side launch: one workgroup (4 waves, each alone on its SIMD) per 256 listed rays, on at most half of the CUs
     ListArgs strict_la;
-    strict_la.list = list_strict;
-    strict_la.n_ptr = counts + 1;
-    strict_la.fixed_grid = (int) std::max<unsigned long long>(1, std::min<unsigned long long>((n_strict + kBlock - 1) / kBlock, (unsigned long long) sc->cus / 2));
-    int rc = launch_f64<false, true>(p, rays, n, c, sc->counters + kCounters, sc->cus, stream, 1, strict_la);
+    strict_la.list = ws->list;
+    strict_la.n_ptr = split_words + 1;
+    strict_la.n_mode = 1;
+    const int64_t list_max = std::min<int64_t>(n, kListCap);
+    strict_la.fixed_grid = (int) std::max<int64_t>(1, std::min<int64_t>((list_max + kBlock - 1) / kBlock, ws->cus / 2));
+    int rc = launch_f64<false, true>(p, rays, list_max, c, ws->counters + kCounters, ws->cus, stream, 1, strict_la);
     if (rc != KR_OK) return rc;
-    KR_HIP(hipStreamWaitEvent(sc->side_stream, sc->ev_classified, 0));
-    ListArgs fast_la;
-    fast_la.skip = strict_mask;
-    rc = fast_main ? launch_f64<true, false>(p, rays, n, c, sc->counters, sc->cus, sc->side_stream, mb ? mb : 3, fast_la)
-                   : launch_f64<false, false>(p, rays, n, c, sc->counters, sc->cus, sc->side_stream, mb ? mb : 3, fast_la);
+    // strict overflow launch (mask == 2): only has work when more than kListCap rays were flagged
+    if (n > kListCap) {
+        ListArgs rest_la;
+        rest_la.n_ptr = split_words + 1;
+        rest_la.n_mode = 2;
+        rest_la.mask = ws->mask;
+        rest_la.mask_want = 2;
+        rc = launch_f64<false, false>(p, rays, n, c, ws->counters + 2 * kCounters, ws->cus, stream, mb, rest_la);
+        if (rc != KR_OK) return rc;
+    }
+    KR_HIP(hipEventRecord(ws->ev_strict1, stream));
+    // main launch
+    KR_HIP(hipStreamWaitEvent(ws->side_stream, ws->ev_classified, 0));
+    KR_HIP(hipEventRecord(ws->ev_main0, ws->side_stream));
+    ListArgs main_la;
+    main_la.mask = ws->mask;
+    main_la.mask_want = 0;
+    rc = fast_main ? launch_f64<true, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, mb ? mb : 3, main_la)
+                   : launch_f64<false, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, mb ? mb : 3, main_la);
     if (rc != KR_OK) return rc;
-    KR_HIP(hipEventRecord(sc->ev_side_done, sc->side_stream));
-    KR_HIP(hipStreamWaitEvent(stream, sc->ev_side_done, 0));
+    KR_HIP(hipEventRecord(ws->ev_main1, ws->side_stream));
+    KR_HIP(hipStreamWaitEvent(stream, ws->ev_main1, 0));
+    ws->split = true;
     return KR_OK;
 }
 
@@ -502,9 +594,7 @@ int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned 
     }
 }
 
-}  // namespace
-
-int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, kr_stats* stats, bool f32)
+int validate(const kr_params* p, void* d_rays, int64_t n)
 {
     if (!p || (n > 0 && !d_rays) || n < 0) { set_error("kr_trace: null argument or negative n"); return KR_EINVAL; }
     if (p->integrator < KR_EULER || p->integrator > KR_RK45) { set_error("kr_trace: unknown integrator"); return KR_EINVAL; }
@@ -514,47 +604,114 @@ int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, k
         set_error("kr_trace: Integrator::Euler does not support RayDestination stopping conditions");
         return KR_EINVAL;
     }
-    int rc = require_device();
+    return require_device();
+}
+
+}  // namespace
+
+// Enqueues one trace on `stream` and returns at once; *ticket (never null on success, unless n == 0) must go to trace_wait or
+// trace_release.  Nothing in here synchronises with the device.
+int trace_async(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, bool f32, void** ticket)
+{
+    *ticket = nullptr;
+    int rc = validate(p, d_rays, n);
     if (rc != KR_OK) return rc;
-    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->rays_total = n; }
     if (n == 0) return KR_OK;
 
     // effective_steplim, raytracer.cpp:80
     const int steplim = (p->steplim > 0) ? p->steplim : (p->integrator == KR_RK45) ? KR_RK45_STEPLIM : KR_STEPLIM;
 
-    DeviceScratch* sc = nullptr;
-    rc = scratch_for_current(&sc);
+    Workspace* ws = nullptr;
+    rc = workspace_acquire(&ws);
     if (rc != KR_OK) return rc;
+    ws->split = false;
+    ws->n = n;
+    auto body = [&]() -> int {
+        KR_HIP(hipMemsetAsync(ws->counters, 0, kCounterBlocks * kCounters * sizeof(unsigned long long), stream));
+        KR_HIP(hipEventRecord(ws->ev0, stream));
+        const bool hybrid = !f32 && (p->flags & KR_FLAG_HYBRID) && !(p->flags & KR_FLAG_FAST_MATH);
+        // all-strict launches of some size isolate their ill-conditioned (in the lamp-post workloads: longest) rays the same way:
+        // identical results, no tail.  KR_NO_ISOLATE=1 keeps the single launch (A/B and bit-identity tests).
+        const bool isolate = !f32 && !hybrid && !(p->flags & KR_FLAG_FAST_MATH) && n >= kIsolateMinRays && !getenv("KR_NO_ISOLATE");
+        int r = f32 ? dispatch<float>(p, d_rays, n, steplim, ws->counters, ws->cus, stream)
+                    : (hybrid || isolate) ? dispatch_split(p, (kr_ray_f64*) d_rays, n, steplim, ws, stream, hybrid)
+                                          : dispatch<double>(p, d_rays, n, steplim, ws->counters, ws->cus, stream);
+        if (r != KR_OK) return r;
+        KR_HIP(hipEventRecord(ws->ev1, stream));
+        KR_HIP(hipMemcpyAsync(ws->h_counters, ws->counters, kCounterBlocks * kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        KR_HIP(hipEventRecord(ws->done, stream));
+        return KR_OK;
+    };
+    rc = body();
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        ws->pending = true;            // (also after a failure part-way: whatever was enqueued must drain before reuse)
+    }
+    if (rc != KR_OK) {
+        (void) hipEventRecord(ws->done, stream);
+        workspace_release(ws);
+        return rc;
+    }
+    *ticket = ws;
+    return KR_OK;
+}
 
-    KR_HIP(hipMemsetAsync(sc->counters, 0, 3 * kCounters * sizeof(unsigned long long), stream));
-    if (stats) KR_HIP(hipEventRecord(sc->ev0, stream));
-    const bool hybrid = !f32 && (p->flags & KR_FLAG_HYBRID) && !(p->flags & KR_FLAG_FAST_MATH);
-    // all-strict launches of some size isolate their ill-conditioned (in the lamp-post workloads: longest) rays the same way:
-    // identical results, no tail.  KR_NO_ISOLATE=1 keeps the single launch (A/B and bit-identity tests).
-    const bool isolate = !f32 && !hybrid && !(p->flags & KR_FLAG_FAST_MATH) && n >= kIsolateMinRays && !getenv("KR_NO_ISOLATE");
-    rc = f32 ? dispatch<float>(p, d_rays, n, steplim, sc->counters, sc->cus, stream)
-             : (hybrid || isolate) ? dispatch_split(p, (kr_ray_f64*) d_rays, n, steplim, sc, stream, hybrid)
-                                   : dispatch<double>(p, d_rays, n, steplim, sc->counters, sc->cus, stream);
-    if (rc != KR_OK) return rc;
-    if (stats) {
-        KR_HIP(hipEventRecord(sc->ev1, stream));
-        unsigned long long h2[3 * kCounters];
-        KR_HIP(hipMemcpyAsync(h2, sc->counters, sizeof(h2), hipMemcpyDeviceToHost, stream));
-        KR_HIP(hipStreamSynchronize(stream));
+// Waits for the trace behind `ticket`, fills *stats (may be null) and returns the workspace to the pool.
+int trace_wait(void* ticket, kr_stats* stats)
+{
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (!ticket) return KR_OK;                       // the n == 0 call
+    Workspace* ws = (Workspace*) ticket;
+    auto body = [&]() -> int {
+        KR_HIP(hipEventSynchronize(ws->done));
+        if (!stats) return KR_OK;
+        const unsigned long long* h2 = ws->h_counters;
         unsigned long long h[kCounters];
-        for (int i = 0; i < kCounters; i++) h[i] = h2[i] + h2[kCounters + i];
-        stats->rays_strict_side = (int64_t) h2[2 * kCounters + 1];
-        float ms = 0;
-        KR_HIP(hipEventElapsedTime(&ms, sc->ev0, sc->ev1));
+        for (int i = 0; i < kCounters; i++) h[i] = h2[i] + h2[kCounters + i] + h2[2 * kCounters + i];
+        stats->rays_total = ws->n;
+        stats->rays_strict_side = (int64_t) h2[3 * kCounters + 1];
         stats->rays_traced = (int64_t) h[1];
         stats->steps_total = (int64_t) h[2];
         stats->rk45_attempts = (int64_t) h[3];
         stats->rk45_rejects = (int64_t) h[4];
         stats->rk45_stationary_steps = (int64_t) h[5];
         stats->rk45_extrapolated_steps = (int64_t) h[6];
+        float ms = 0;
+        KR_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
         stats->kernel_ms = ms;
+        if (ws->split) {
+            KR_HIP(hipEventElapsedTime(&ms, ws->ev_strict0, ws->ev_strict1));
+            stats->strict_side_ms = ms;
+            KR_HIP(hipEventElapsedTime(&ms, ws->ev_main0, ws->ev_main1));
+            stats->main_ms = ms;
+        }
+        return KR_OK;
+    };
+    const int rc = body();
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (rc == KR_OK) ws->pending = false;
+        ws->leased = false;
     }
-    return KR_OK;
+    return rc;
+}
+
+// Gives the ticket back without waiting: the workspace is reused once its trace has finished.
+void trace_release(void* ticket)
+{
+    if (ticket) workspace_release((Workspace*) ticket);
+}
+
+int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, kr_stats* stats, bool f32)
+{
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->rays_total = n; }
+    void* ticket = nullptr;
+    const int rc = trace_async(p, d_rays, n, stream, f32, &ticket);
+    if (rc != KR_OK) return rc;
+    if (!stats) { trace_release(ticket); return KR_OK; }
+    const int rc2 = trace_wait(ticket, stats);
+    stats->rays_total = n;
+    return rc2;
 }
 
 }  // namespace kr

@@ -1,0 +1,144 @@
+"""GPU: several traces in flight on one device (kr_trace_async_* / kr_trace_wait; per-call workspaces, include/kr_trace.h).
+
+The multi-launch drivers of the reference -- one run_raytrace per source radius (src/return_radiation/
+disc_source_photonfrac_r.cpp:74-92), one per tolerance (src/tests/emissivity_rk45_tol_sweep.py:38) -- are the callers that
+want their launches to overlap.  Overlapping traces on different streams must give, ray for ray and bit for bit, what the
+same traces give one after the other, and each ticket must report its own counters."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bench
+from raytrace_cpu_amd import api, capi
+
+pytestmark = pytest.mark.gpu
+
+
+class DeviceRays:
+    """A device buffer holding a PointSource grid, initialised on the device."""
+
+    def __init__(self, lib, spec, V=0.0):
+        self.lib, self.spec = lib, spec
+        self.n = api.pointsource_count(spec)[0]
+        self.d = C.c_void_p()
+        capi.check(lib, lib.kr_malloc(C.byref(self.d), self.n * capi.RAY_F64.itemsize), "kr_malloc")
+        self.V = V
+
+    def init(self, stream=None):
+        capi.check(self.lib, self.lib.kr_pointsource_init_emit_dev_f64(C.byref(self.spec), 0, 1, self.V, 0, 0, self.d, self.n, C.c_void_p(stream or 0)), "init")
+
+    def fetch(self):
+        out = np.zeros(self.n, dtype=capi.RAY_F64)
+        capi.check(self.lib, self.lib.kr_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.d, out.nbytes), "d2h")
+        return out
+
+    def free(self):
+        self.lib.kr_free(self.d)
+
+
+def same_bits(a, b):
+    return all((a[f].view(np.int64) == b[f].view(np.int64)).all() if a[f].dtype.kind == "f" else (a[f] == b[f]).all() for f in a.dtype.names)
+
+
+@pytest.mark.parametrize("flags", [pytest.param(capi.FLAG_HYBRID, id="hybrid"), pytest.param(0, id="strict-split")])
+def test_overlapping_traces_equal_sequential_ones(krlib, flags):
+    lib = krlib
+    # two different lamp-post grids, both large enough for the split launch (>= 2^18 rays)
+    specs = [bench.make_spec(capi, bench.grid_spacing_for(4.0e5)), bench.make_spec(capi, bench.grid_spacing_for(6.0e5))]
+    specs[1].pos[1] = 5.0
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, bench.R_MAX, flags
+    bufs = [DeviceRays(lib, s) for s in specs]
+    try:
+        # sequential reference: default stream, one after the other, each waited for
+        want, want_st = [], []
+        for b in bufs:
+            b.init()
+            want_st.append(api.trace_dev(p, b.d.value, b.n))
+            want.append(b.fetch())
+        assert all(st["rays_strict_side"] > 0 for st in want_st)            # the split path, with its side launch
+        # overlapped: two streams, both traces enqueued before either is waited for; three rounds so that workspaces get reused
+        streams = []
+        for _ in bufs:
+            s = C.c_void_p()
+            capi.check(lib, lib.kr_stream_create(C.byref(s)), "stream")
+            streams.append(s)
+        for rnd in range(3):
+            tickets = []
+            for b, s in zip(bufs, streams):
+                b.init(s.value)
+                tickets.append(api.trace_async(p, b.d.value, b.n, stream=s.value))
+            stats = [api.trace_wait(t) for t in reversed(tickets)][::-1]      # waited for in the opposite order
+            for b, w, st, wst in zip(bufs, want, stats, want_st):
+                got = b.fetch()
+                assert same_bits(got, w), f"round {rnd}: overlapped trace differs from the sequential one"
+                for k in ("rays_total", "rays_traced", "steps_total", "rays_strict_side"):
+                    assert st[k] == wst[k], (k, st[k], wst[k])
+                assert st["kernel_ms"] > 0 and st["strict_side_ms"] > 0 and st["main_ms"] > 0
+        for s in streams:
+            lib.kr_stream_destroy(s)
+    finally:
+        for b in bufs:
+            b.free()
+
+
+def test_fire_and_forget_calls_on_many_streams(krlib):
+    """kr_trace_dev_f64(stats = NULL) from a loop over four streams, more calls than streams: every buffer ends up traced."""
+    lib = krlib
+    spec = bench.make_spec(capi, bench.grid_spacing_for(3.0e5))
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, bench.R_MAX, capi.FLAG_HYBRID
+    bufs = [DeviceRays(lib, spec) for _ in range(8)]
+    streams = []
+    try:
+        for _ in range(4):
+            s = C.c_void_p()
+            capi.check(lib, lib.kr_stream_create(C.byref(s)), "stream")
+            streams.append(s)
+        for i, b in enumerate(bufs):
+            s = streams[i % 4]
+            b.init(s.value)
+            assert api.trace_dev(p, b.d.value, b.n, stream=s.value, want_stats=False) is None
+        for s in streams:
+            capi.check(lib, lib.kr_synchronize(s), "sync")
+        first = bufs[0].fetch()
+        assert (first["steps"][first["steps"] != -1] != 0).all()
+        for b in bufs[1:]:
+            assert same_bits(b.fetch(), first)
+    finally:
+        for s in streams:
+            lib.kr_stream_destroy(s)
+        for b in bufs:
+            b.free()
+
+
+def test_list_overflow_goes_to_the_ordinary_strict_launch(krlib):
+    """A source made only of ill-conditioned rays (every ray in the beta = -pi meridional plane) flags more rays than the side
+    launch's list holds; the overflow launch must trace the rest, with the bits of a plain strict launch."""
+    lib = krlib
+    import math
+    spec = bench.make_spec(capi, 1.99 / 299999.0)                # 3e5 values of cos(alpha) ...
+    spec.beta0, spec.betamax, spec.dbeta = -math.pi, -math.pi + 1e-9, 1.0       # ... in one column
+    n = api.pointsource_count(spec)[0]
+    assert n >= (1 << 18)
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max, p.steplim = capi.RK4, bench.R_MAX, 400            # (bounded: these are the polar-axis rays)
+    b = DeviceRays(lib, spec)
+    try:
+        import os
+        b.init()
+        st = api.trace_dev(p, b.d.value, b.n)
+        got = b.fetch()
+        assert st["rays_strict_side"] == st["rays_traced"] > 32768
+        os.environ["KR_NO_ISOLATE"] = "1"
+        try:
+            b.init()
+            st1 = api.trace_dev(p, b.d.value, b.n)
+            want = b.fetch()
+        finally:
+            del os.environ["KR_NO_ISOLATE"]
+        assert st1["rays_strict_side"] == 0 and st1["steps_total"] == st["steps_total"]
+        assert same_bits(got, want)
+    finally:
+        b.free()

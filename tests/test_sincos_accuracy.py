@@ -14,6 +14,11 @@ def test_compact_sincos_error_bounds(tmp_path):
         assert ms < 1.0 and mc < 1.0, (args, ms, mc)          # vs long double
         assert gs <= 1.0 and gcs <= 1.0, (args, gs, gcs)      # vs glibc double
         assert es > 0.95 and ec > 0.95                         # and bit-equal to glibc for > 95 % of arguments
+    # the small-angle branch (|x| < 2^-7, kr_sincos_small_f64): polar-axis rays live there for their whole life
+    for args in (["2000000", "-0.0078125", "0.0078125"], ["1000000", "0.00099999", "0.00100001"], ["500000", "-1e-9", "1e-9"]):
+        n, ms, mc, gs, gcs, es, ec = (float(x) for x in subprocess.check_output([exe] + args, text=True).split())
+        assert gs <= 1.0 and gcs <= 1.0, (args, gs, gcs)
+        assert es > 0.9999 and ec > 0.9999, (args, es, ec)     # correctly rounded in practice: bit-equal to glibc
 
 
 def test_fast_path_sincos_error_bounds(tmp_path):
