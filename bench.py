@@ -273,32 +273,65 @@ class ReturnRadiationWorkload:
             s.cosalpha0, s.cosalphamax, s.dcosalpha = -0.995, 0.995, d
             s.beta0, s.betamax, s.dbeta = 0.0, math.pi, d * (math.pi / 2) / 0.995
             self.specs.append(s)
-        self.n = max(api.pointsource_count(s)[0] for s in self.specs)
+        self.counts = [api.pointsource_count(s)[0] for s in self.specs]
+        self.n = max(self.counts)
+        self.nstreams, self.streams, self.buffers, self.order, self.ordered = max(1, args.streams), None, None, None, False
         self.p = capi.default_params(SPIN)
         self.p.integrator, self.p.r_max = self.method, 1.1 * R_MAX
         self.result_words = 4 * self.nr
         self.describe = (f"disc->disc returning radiation: {self.nr} source radii r_isco..500 x ~{int(rays)} rays (beta in [0,pi)), {args.integrator.upper()}, "
                          f"r_max=1.1*r_esc, per-radius relaunch (BASELINE configs[4])")
-        self.pipeline = "per radius: [pointsource_init+redshift_start]+trace+range_phi+return_classification"
+        self.pipeline = (f"per radius: [pointsource_init+redshift_start]+trace+range_phi+return_classification; radii round-robin over {self.nstreams} stream(s), "
+                         "longest launches first, one counter read-back at the end")
         self.sharding = f"radii cyclic over {world} rank(s)"
 
     def step(self, d_rays, d_res, stream):
+        """Radii go round-robin over self.nstreams HIP streams (each with its own ray buffer), the radii whose launches have the
+        longest tails first, so that the long-ray tail of one radius overlaps the bulk of the next ones; counters are collected
+        once, after the last radius (kr_trace_async / kr_trace_wait).  --streams 1 is the old serial relaunch loop."""
+        import torch
         lib, capi, vp = self.lib, self.capi, C.c_void_p
-        tot = None
-        for (ir, r_s), s in zip(self.radii, self.specs):
-            n = self.api.pointsource_count(s)[0]
-            capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(s), 0, 1, s.V, 0, 0, vp(d_rays), n, vp(stream)), "init+redshift_start (fused)")
-            st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
-            capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(d_rays), n, vp(stream)), "range_phi")
+        if self.streams is None:
+            self.streams = [torch.cuda.Stream() for _ in range(self.nstreams)] if self.nstreams > 1 else []
+            self.buffers = [torch.empty(self.n * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda") for _ in self.streams]
+            self.order = list(range(len(self.radii)))
+        cur = torch.cuda.current_stream()
+        lanes = [(s.cuda_stream, b.data_ptr()) for s, b in zip(self.streams, self.buffers)] or [(stream, d_rays)]
+        for s in self.streams:
+            s.wait_stream(cur)                       # behind the zeroing of the result table
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(cur)
+        tickets = []
+        for k, j in enumerate(self.order):
+            (ir, r_s), s = self.radii[j], self.specs[j]
+            st_k, rays_k = lanes[k % len(lanes)]
+            n = self.counts[j]
+            capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(s), 0, 1, s.V, 0, 0, vp(rays_k), n, vp(st_k)), "init+redshift_start (fused)")
+            tickets.append((j, self.api.trace_async(self.p, rays_k, n, stream=st_k)))
+            capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(rays_k), n, vp(st_k)), "range_phi")
             b = capi.ReturnBins()
             b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, r_s, 1.5707
             b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
-            capi.check(lib, lib.kr_reduce_return_dev_f64(C.byref(b), vp(d_rays), n, vp(d_res + 32 * ir), vp(stream)), "reduce")
+            capi.check(lib, lib.kr_reduce_return_dev_f64(C.byref(b), vp(rays_k), n, vp(d_res + 32 * ir), vp(st_k)), "reduce")
+        for s in self.streams:
+            cur.wait_stream(s)                       # whatever follows on the caller's stream (the all-reduce) sees every radius
+        t1.record(cur)
+        tot, per = None, {}
+        for j, t in tickets:
+            st = self.api.trace_wait(t)
+            per[j] = st["kernel_ms"]
             if tot is None:
                 tot = dict(st)
             else:
-                for k in ("rays_traced", "steps_total", "rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "rk45_extrapolated_steps", "kernel_ms"):
-                    tot[k] += st[k]
+                for key in ("rays_traced", "steps_total", "rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "rk45_extrapolated_steps", "kernel_ms"):
+                    tot[key] += st[key]
+        t1.synchronize()
+        tot["sum_of_launch_ms"] = tot["kernel_ms"]
+        tot["kernel_ms"] = t0.elapsed_time(t1)       # the span the overlapping launches took together, HIP events on the caller's stream
+        if not self.ordered and self.streams:
+            # first pass: from now on, longest launch first (a launch's length beyond the mean is its long-ray tail)
+            self.order = sorted(self.order, key=lambda j: -per[j])
+            self.ordered = True
         return tot
 
     def summary(self, h):
@@ -316,6 +349,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="emissivity", choices=["emissivity", "imageplane", "return_radiation"])
     ap.add_argument("--radii", type=int, default=100, help="return_radiation: number of source radii")
+    ap.add_argument("--streams", type=int, default=4, help="return_radiation: HIP streams the per-radius launches are spread over (1 = serial relaunch)")
     ap.add_argument("--rays", type=float, default=0, help="rays per GPU (default: 1e7 emissivity = BASELINE configs[1]; 4097^2 imageplane = configs[3])")
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
     ap.add_argument("--arithmetic", default="auto", choices=["auto", "hybrid", "strict", "fast"],
@@ -420,7 +454,9 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         avg_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        units = stats_last["rk45_attempts"] if args.integrator == "rk45" else steps_total     # RK45 work unit = one trial step
+        # RK45 work unit = one EVALUATED trial step (7 derivative evaluations): the steps of captured rays that are replayed as bare
+        # t / phi additions (rk45_stationary_steps) or extrapolated in creep mode (k1 only; rk45_extrapolated_steps) are not priced
+        units = (stats_last["rk45_attempts"] - stats_last["rk45_stationary_steps"] - stats_last["rk45_extrapolated_steps"]) if args.integrator == "rk45" else steps_total
         flop = FLOP_PER_STEP[args.integrator] * units                                            # this rank's launch
         achieved_tflops = flop / (avg_kernel_ms * 1e-3) / 1e12
         traffic = None
@@ -442,6 +478,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
                          "flop_per_step": FLOP_PER_STEP[args.integrator], "work_units_per_launch": int(units), "avg_kernel_ms": avg_kernel_ms,
                          "kernel_steps_per_sec": steps_total / (avg_kernel_ms * 1e-3),
+                         "split_launch_ms": {"strict_side": stats_last.get("strict_side_ms", 0.0), "main": stats_last.get("main_ms", 0.0)},
                          "hbm": {"algorithmic_bytes": 288 * int(traced), "achieved_gbs": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9,
                                  "peak_gbs": HBM_PEAK_GBS, "frac": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "traffic": traffic,
@@ -452,6 +489,7 @@ def main():
             out["other_arithmetic_modes"] = others
         if args.integrator == "rk45":
             out["rk45"] = {k: int(stats_last[k]) for k in ("rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "rk45_extrapolated_steps")}
+            out["rk45"]["evaluated_trial_steps"] = int(units)
         if world > 1:
             pass                                    # cpu_baseline is an N = 1 leg only
         elif not args.no_cpu_baseline and args.workload == "emissivity":

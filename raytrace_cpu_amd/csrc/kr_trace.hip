@@ -507,7 +507,8 @@ int launch_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, const TraceConst
 // Nothing here waits for the device: how many rays were flagged stays in device memory (counters block 3, word 1) and the
 // launches read it there.  The side launch is sized for the worst case the list can hold (workgroups that find the queue
 // empty leave at once); a source made mostly of ill-conditioned rays (all rays in one meridional plane, say) overflows the
-// list, and the overflow -- mask value 2 -- is traced by a third, ordinary-occupancy strict launch that is a no-op otherwise.
+// list, and the overflow -- mask value 2 -- is traced by a third, ordinary-occupancy strict launch that is a no-op otherwise
+// (its workgroups read the count and leave).
 int dispatch_split(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream, bool fast_main)
 {
     if (n > 0x7fffffff) { set_error("kr_trace: the split path indexes rays with 32 bits"); return KR_EINVAL; }
@@ -536,16 +537,6 @@ int dispatch_split(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim,
     strict_la.fixed_grid = (int) std::max<int64_t>(1, std::min<int64_t>((list_max + kBlock - 1) / kBlock, ws->cus / 2));
     int rc = launch_f64<false, true>(p, rays, list_max, c, ws->counters + kCounters, ws->cus, stream, 1, strict_la);
     if (rc != KR_OK) return rc;
-    // strict overflow launch (mask == 2): only has work when more than kListCap rays were flagged
-    if (n > kListCap) {
-        ListArgs rest_la;
-        rest_la.n_ptr = split_words + 1;
-        rest_la.n_mode = 2;
-        rest_la.mask = ws->mask;
-        rest_la.mask_want = 2;
-        rc = launch_f64<false, false>(p, rays, n, c, ws->counters + 2 * kCounters, ws->cus, stream, mb, rest_la);
-        if (rc != KR_OK) return rc;
-    }
     KR_HIP(hipEventRecord(ws->ev_strict1, stream));
     // main launch
     KR_HIP(hipStreamWaitEvent(ws->side_stream, ws->ev_classified, 0));
@@ -556,6 +547,18 @@ int dispatch_split(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim,
     rc = fast_main ? launch_f64<true, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, mb ? mb : 3, main_la)
                    : launch_f64<false, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, mb ? mb : 3, main_la);
     if (rc != KR_OK) return rc;
+    // strict overflow launch (mask == 2): only has work when more than kListCap rays were flagged, and then the main launch has
+    // next to none.  It follows the main launch on the side stream: behind the side launch on the caller's stream its idle
+    // workgroups would sit waiting for the main launch's registers (measured: 10 ms of "kernel time" doing nothing).
+    if (n > kListCap) {
+        ListArgs rest_la;
+        rest_la.n_ptr = split_words + 1;
+        rest_la.n_mode = 2;
+        rest_la.mask = ws->mask;
+        rest_la.mask_want = 2;
+        rc = launch_f64<false, false>(p, rays, n, c, ws->counters + 2 * kCounters, ws->cus, ws->side_stream, mb, rest_la);
+        if (rc != KR_OK) return rc;
+    }
     KR_HIP(hipEventRecord(ws->ev_main1, ws->side_stream));
     KR_HIP(hipStreamWaitEvent(stream, ws->ev_main1, 0));
     ws->split = true;

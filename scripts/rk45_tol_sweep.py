@@ -2,8 +2,12 @@
 """BASELINE configs[2]: adaptive RK45 tolerance sweep (reference src/tests/emissivity_rk45_tol_sweep.py:38 tolerances,
 src/tests/emissivity_rk45_plot.cpp:35-38 grid 0.01 x 0.01 = 125 863 allocated rays), source h = 5 (the reference's
 sweep) and h = 10 (BASELINE), on one MI355X through the C ABI.  Prints one JSON document.
-RK4 on the same grid is run beside it so the RK4-vs-RK45 emissivity deviation the reference's sweep plots can be formed."""
-import json, math, os, sys
+RK4 on the same grid is run beside it so the RK4-vs-RK45 emissivity deviation the reference's sweep plots can be formed.
+After the point-by-point pass, all 18 points (2 heights x 9 tolerances) are run AT ONCE, device-resident, one stream and
+one ray buffer each (kr_trace_async_f64 / kr_trace_wait): their long-ray tails overlap, so the whole sweep should cost little
+more than its slowest point ("concurrent" in the output).
+usage: rk45_tol_sweep.py [hybrid|strict|fast]"""
+import ctypes as C, json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import bench
@@ -51,4 +55,53 @@ for h in (5.0, 10.0):
         out["runs"].append({"h": h, "integrator": "rk45", "tol": tol, "rays": st["rays_traced"], "steps": st["steps_total"], "attempts": st["rk45_attempts"], "rejects": st["rk45_rejects"],
                             "stationary_steps": st["rk45_stationary_steps"], "extrapolated_steps": st["rk45_extrapolated_steps"], "kernel_ms": st["kernel_ms"], "steps_per_sec": st["steps_total"] / st["kernel_ms"] * 1e3,
                             "attempts_per_sec": st["rk45_attempts"] / st["kernel_ms"] * 1e3, "emis_dev_vs_rk4_rms": float(np.sqrt(np.mean(dev ** 2))), "emis_dev_vs_rk4_max": float(dev.max())})
+
+# ---- the same 18 points, all in flight together -------------------------------------------------------------------------
+lib = api.lib()
+vp = C.c_void_p
+points = []
+for h in (5.0, 10.0):
+    spec = capi.PointSourceSpec()
+    for i, v in enumerate([0.0, h, 1e-3, 0.0]): spec.pos[i] = v
+    spec.V, spec.spin, spec.tol, spec.E = 0.0, gc.SPIN, 100.0, 1.0
+    spec.cosalpha0, spec.cosalphamax, spec.dcosalpha = -0.995, 0.995, 0.01
+    spec.beta0, spec.betamax, spec.dbeta = -math.pi, math.pi, 0.01
+    n = api.pointsource_count(spec)[0]
+    bins = gc.emis_bins(spec, nr=30)
+    for tol in TOLS:
+        d_rays, d_hist, stream = vp(), vp(), vp()
+        capi.check(lib, lib.kr_malloc(C.byref(d_rays), n * capi.RAY_F64.itemsize), "malloc")
+        capi.check(lib, lib.kr_malloc(C.byref(d_hist), (5 * bins.nr + 1) * 8), "malloc")
+        capi.check(lib, lib.kr_stream_create(C.byref(stream)), "stream")
+        p = capi.default_params(gc.SPIN); p.integrator, p.rk45_tol, p.flags = capi.RK45, tol, ARITH
+        points.append(dict(h=h, tol=tol, spec=spec, n=n, bins=bins, d_rays=d_rays, d_hist=d_hist, stream=stream, p=p))
+
+def enqueue(pt):
+    capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(pt["spec"]), 0, 1, 0.0, 0, 0, pt["d_rays"], pt["n"], pt["stream"]), "init")
+    t = api.trace_async(pt["p"], pt["d_rays"].value, pt["n"], stream=pt["stream"].value)
+    capi.check(lib, lib.kr_post_emissivity_dev_f64(gc.SPIN, -1.0, 0, 0, 0, -math.pi, math.pi, C.byref(pt["bins"]), pt["d_rays"], pt["n"], pt["d_hist"], pt["stream"]), "post")
+    return t
+
+walls = []
+for rnd in range(3):
+    for pt in points:
+        capi.check(lib, lib.kr_memset(pt["d_hist"], 0, (5 * pt["bins"].nr + 1) * 8), "memset")
+    capi.check(lib, lib.kr_synchronize(None), "sync")
+    t0 = time.perf_counter()
+    tickets = [enqueue(pt) for pt in points]
+    stats = [api.trace_wait(t) for t in tickets]
+    for pt in points:
+        capi.check(lib, lib.kr_synchronize(pt["stream"]), "sync")
+    walls.append(1e3 * (time.perf_counter() - t0))
+serial = {(r["h"], r["tol"]): r["kernel_ms"] for r in out["runs"] if r["integrator"] == "rk45"}
+hist_ok = True
+for pt, st in zip(points, stats):
+    hh = np.zeros(5 * pt["bins"].nr + 1)
+    capi.check(lib, lib.kr_memcpy_d2h(hh.ctypes.data_as(vp), pt["d_hist"], hh.nbytes), "d2h")
+    hist_ok = hist_ok and hh[-1] > 0 and st["steps_total"] == [r for r in out["runs"] if r["integrator"] == "rk45" and r["h"] == pt["h"] and r["tol"] == pt["tol"]][0]["steps"]
+out["concurrent"] = {"points": len(points), "wall_ms_rounds": walls, "wall_ms": min(walls), "slowest_single_point_ms": max(serial.values()), "sum_of_single_points_ms": sum(serial.values()),
+                     "wall_over_slowest_point": min(walls) / max(serial.values()), "per_point_span_ms": [st["kernel_ms"] for st in stats],
+                     "same_step_totals_as_point_by_point": bool(hist_ok)}
+for pt in points:
+    lib.kr_free(pt["d_rays"]); lib.kr_free(pt["d_hist"]); lib.kr_stream_destroy(pt["stream"])
 print(json.dumps(out, indent=1))
