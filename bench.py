@@ -297,16 +297,21 @@ class ReturnRadiationWorkload:
             self.order = list(range(len(self.radii)))
         cur = torch.cuda.current_stream()
         lanes = [(s.cuda_stream, b.data_ptr()) for s, b in zip(self.streams, self.buffers)] or [(stream, d_rays)]
+        if not self.ordered:
+            lanes = [(stream, d_rays)]               # first (warm-up) pass: one launch at a time, to learn each radius's own launch time
         for s in self.streams:
             s.wait_stream(cur)                       # behind the zeroing of the result table
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record(cur)
-        tickets = []
+        tickets, done = [], []
         for k, j in enumerate(self.order):
             (ir, r_s), s = self.radii[j], self.specs[j]
             st_k, rays_k = lanes[k % len(lanes)]
             n = self.counts[j]
             capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(s), 0, 1, s.V, 0, 0, vp(rays_k), n, vp(st_k)), "init+redshift_start (fused)")
+            if len(tickets) - len(done) >= 4 * len(lanes):          # bounded pipeline depth: collect the oldest launch's counters
+                jj, tt = tickets[len(done)]
+                done.append((jj, self.api.trace_wait(tt)))
             tickets.append((j, self.api.trace_async(self.p, rays_k, n, stream=st_k)))
             capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(rays_k), n, vp(st_k)), "range_phi")
             b = capi.ReturnBins()
@@ -317,8 +322,8 @@ class ReturnRadiationWorkload:
             cur.wait_stream(s)                       # whatever follows on the caller's stream (the all-reduce) sees every radius
         t1.record(cur)
         tot, per = None, {}
-        for j, t in tickets:
-            st = self.api.trace_wait(t)
+        done += [(j, self.api.trace_wait(t)) for j, t in tickets[len(done):]]
+        for j, st in done:
             per[j] = st["kernel_ms"]
             if tot is None:
                 tot = dict(st)

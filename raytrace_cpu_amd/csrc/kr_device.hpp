@@ -854,19 +854,19 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     sum_t = sum_t + D::b3 * pt_i;
     sum_phi = sum_phi + D::b3 * pphi_i;
 
-    momentum(pt_i, pr4, ptheta4, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign,
+    eval<T, FAST>(pt_i, pr4, ptheta4, pphi_i, s,
              r + h_try * (D::a41 * pr1 + D::a42 * pr2 + D::a43 * pr3),
              theta + h_try * (D::a41 * ptheta1 + D::a42 * ptheta2 + D::a43 * ptheta3), a);
     sum_t = sum_t + D::b4 * pt_i;
     sum_phi = sum_phi + D::b4 * pphi_i;
 
-    momentum(pt_i, pr5, ptheta5, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign,
+    eval<T, FAST>(pt_i, pr5, ptheta5, pphi_i, s,
              r + h_try * (D::a51 * pr1 + D::a52 * pr2 + D::a53 * pr3 + D::a54 * pr4),
              theta + h_try * (D::a51 * ptheta1 + D::a52 * ptheta2 + D::a53 * ptheta3 + D::a54 * ptheta4), a);
     sum_t = sum_t + D::b5 * pt_i;
     sum_phi = sum_phi + D::b5 * pphi_i;
 
-    momentum(pt_i, pr6, ptheta6, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign,
+    eval<T, FAST>(pt_i, pr6, ptheta6, pphi_i, s,
              r + h_try * (D::a61 * pr1 + D::a62 * pr2 + D::a63 * pr3 + D::a64 * pr4 + D::a65 * pr5),
              theta + h_try * (D::a61 * ptheta1 + D::a62 * ptheta2 + D::a63 * ptheta3 + D::a64 * ptheta4 + D::a65 * ptheta5), a);
     sum_t = sum_t + D::b6 * pt_i;

@@ -261,7 +261,9 @@ pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_poin
     const long long n_grid = (long long) n_cosalpha * n_beta;
     const double a = reverse ? -1 * s.spin : s.spin;
     if (V == -1) {
-        const kr_ray_f64 r0 = pointsource_ray(s, n_grid, n_beta, first);
+        // the reference's loop overwrites V with the orbital velocity at rays[0] of the WHOLE source and keeps it for every ray
+        // (raytracer.cpp:389-393): source ray 0, not this shard's first ray
+        const kr_ray_f64 r0 = pointsource_ray(s, n_grid, n_beta, 0);
         V = keplerian_V(a, r0.r, r0.theta, projradius != 0);
     }
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
@@ -347,7 +349,7 @@ imageplane_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_image
     const double D = s.dist, incl = s.inc_deg * kPi / 180, phi0 = s.phi0;
     const double am = reverse ? -1 * spin : spin;
     if (V == -1) {
-        const kr_ray_f64 r0 = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, first);
+        const kr_ray_f64 r0 = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, 0);      // source ray 0 (raytracer.cpp:389-393), not the shard's first
         V = keplerian_V(am, r0.r, r0.theta, projradius != 0);
     }
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {

@@ -150,6 +150,10 @@ void Raytracer<T>::run_raytrace(RayDestination<T>* dest, Integrator method, T r_
 }
 
 // ---- single-ray forms --------------------------------------------------------------------------------------
+// The reference's propagate*() take the ray as it is: no skip rule (a ray with steps == -1, or one already past the step limit, is
+// traced all the same; that rule lives in run_raytrace, raytracer.cpp:116-117) and `steplim` verbatim (<= 0: zero iterations and
+// RAY_STATUS_STEPLIM, :172 / :315-316).  The kernel implements run_raytrace, so the ray is staged with a zero step count, which
+// always passes the skip rule, and the epilogue's bookkeeping (:335-337) is redone here on the caller's own count.
 #define KR_SINGLE(method_, theta_expr, dest_expr)                                                       \
     no_outfile(outfile);                                                                                \
     (void) write_step; (void) write_rmax; (void) write_rmin; (void) write_cartesian;                   \
@@ -158,8 +162,17 @@ void Raytracer<T>::run_raytrace(RayDestination<T>* dest, Integrator method, T r_
     theta_expr;                                                                                         \
     dest_expr;                                                                                          \
     const int before = rays[ray].steps;                                                                 \
-    trace(&p, &rays[ray], 1);                                                                           \
-    return std::abs(rays[ray].steps) - std::abs(before);
+    int taken = 0;                                                                                      \
+    if (steplim <= 0) {                                                                                 \
+        rays[ray].status |= KR_STATUS_STEPLIM;                                                          \
+    } else {                                                                                            \
+        rays[ray].steps = 0;                                                                            \
+        trace(&p, &rays[ray], 1);                                                                       \
+        taken = std::abs(rays[ray].steps);                                                              \
+    }                                                                                                   \
+    rays[ray].steps = before + taken;                                                                   \
+    if (rays[ray].status & KR_STATUS_STEPLIM) rays[ray].steps = -rays[ray].steps;                       \
+    return taken;
 
 template <typename T>
 int Raytracer<T>::propagate(int ray, const T rlim, const T thetalim, const int steplim, TextOutput* outfile, int write_step, T write_rmax,

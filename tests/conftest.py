@@ -18,3 +18,12 @@ def krlib():
     """The HIP shared library behind the C ABI; session-wide.  Fails (not skips) when it cannot be loaded."""
     from raytrace_cpu_amd import capi
     return capi.load()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs leave the measured parity margins behind (tests/parity.py::record_margin)."""
+    try:
+        import parity
+        parity.dump_margins(os.path.join(ROOT, "gpurun_out", "parity_margins.json"))
+    except Exception:
+        pass

@@ -40,6 +40,26 @@ int main()
             ++moved;
         }
         CHECK(moved > 10, "too few rays compared");
+        // the single-ray forms have no skip rule and take steplim verbatim (reference raytracer.cpp:129-340): a ray marked
+        // unused (steps == -1) is traced all the same, and steplim <= 0 means zero iterations + RAY_STATUS_STEPLIM
+        PointSource<double> c(pos, 0.0, spin, TOL, 0.2, 0.2, -0.995, 0.995, -M_PI, M_PI);
+        int live = -1;
+        for (int i = 0; i < c.get_count(); i++) if (c.rays[i].steps == 0 && a.rays[i].steps > 5) { live = i; break; }
+        CHECK(live >= 0, "no live ray found");
+        c.rays[live].steps = -1;
+        const int st1 = c.propagate_rk4(live, 1000.0, M_PI_2, STEPLIM);
+        CHECK(st1 == a.rays[live].steps && c.rays[live].steps == st1 - 1 && c.rays[live].r == a.rays[live].r, "steps == -1 ray: returned %d, record %d (run_raytrace took %d)", st1,
+              c.rays[live].steps, a.rays[live].steps);
+        PointSource<double> z(pos, 0.0, spin, TOL, 0.2, 0.2, -0.995, 0.995, -M_PI, M_PI);
+        const double r_before = z.rays[live].r;
+        z.rays[live].steps = 7;
+        const int st0 = z.propagate_rk4(live, 1000.0, M_PI_2, 0);
+        CHECK(st0 == 0 && z.rays[live].r == r_before && (z.rays[live].status & RAY_STATUS_STEPLIM) && z.rays[live].steps == -7, "steplim = 0: returned %d, steps %d status %d", st0,
+              z.rays[live].steps, z.rays[live].status);
+        // a bounded call followed by the rest equals the one-shot result
+        PointSource<double> h2(pos, 0.0, spin, TOL, 0.2, 0.2, -0.995, 0.995, -M_PI, M_PI);
+        const int part = h2.propagate_rk4(live, 1000.0, M_PI_2, 3);
+        CHECK(part == 3 && h2.rays[live].steps == -3, "bounded call: returned %d, steps %d", part, h2.rays[live].steps);
     }
 
     // 2. the float instantiation traces on the GPU too and lands near the double result

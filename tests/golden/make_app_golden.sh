@@ -23,13 +23,16 @@ $APPS/imageplane_disc_image_isco --parfile=$G/imageplane_isco.par --outfile=$G/i
 rm -f $G/imageplane_rk4.fits $G/imageplane_rk45.fits
 $APPS/imageplane_disc_image --parfile=$G/imageplane_rk4.par  --outfile=$G/imageplane_rk4.fits  > /dev/null
 $APPS/imageplane_disc_image --parfile=$G/imageplane_rk45.par --outfile=$G/imageplane_rk45.fits > /dev/null
-for c in caustic_discplane caustic_discplane_rk45 caustic_sourceplane; do
+for c in caustic_discplane caustic_discplane_rk45 caustic_sourceplane caustic_plane; do
     rm -f $G/$c.fits
     app=${c%_rk45}
     $APPS/$app --parfile=$G/$c.par --outfile=$G/$c.fits > /dev/null
 done
 # BASELINE configs[2]: one point (tol = 1e-8) of the RK45 tolerance sweep, src/tests/emissivity_rk45_plot.cpp
 $APPS/emissivity_rk45_plot $G/emissivity_rk45_plot.csv 1e-8 > /dev/null
+# ... and the two ends of that sweep (src/tests/emissivity_rk45_tol_sweep.py:38)
+$APPS/emissivity_rk45_plot $G/emissivity_rk45_plot_tol1e-6.csv 1e-6 > /dev/null
+$APPS/emissivity_rk45_plot $G/emissivity_rk45_plot_tol1e-10.csv 1e-10 > /dev/null
 # src/tests/integrator_perf_test.cpp: the step statistics of its report (timing lines left out)
 $APPS/integrator_perf_test | grep -E "^(Total rays|Valid rays|Invalid rays|Steps per ray|Total steps|Total func)" > $G/integrator_perf_test.txt
 $APPS/raytrace_rk4_test    | tail -16 > $G/raytrace_rk4_test.txt

@@ -6,7 +6,8 @@ What "parity" means here (stated once, used by every test):
   from the CPU reference only through the device libm (sin, cos: <= 1-2 ulp from glibc).  A 1-ulp input
   difference grows along the trajectory; for ordinary rays it stays near 1e-13 relative, for rays that orbit
   near the photon sphere it is amplified exponentially, exactly as between two CPU libms.
-* per ray: integer outputs (status, rdot_flips, equatorial_crossings) equal and |steps| within +-2;
+* per ray: integer outputs (status, rdot_flips, equatorial_crossings) equal; step count EQUAL for Euler / RK4 on the strict
+  and hybrid arithmetic, within +-2 for RK45 and for the opt-in fast arithmetic (steps_slack_for);
   t, r, theta, phi, redshift within RAY_RTOL relative (absolute for |x| < 1): 1e-9 for the fixed-step
   integrators, 1e-7 for RK45, whose step controller divides by an error estimate that is a cancellation of
   O(1) terms down to O(tol) and therefore turns 1 ulp into ~1e-10..1e-8 of step size.  These bands are the
@@ -38,9 +39,16 @@ def rtol_for(params):
     return RAY_RTOL_RK45 if params.integrator == capi.RK45 else RAY_RTOL
 
 
-def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False):
+def steps_slack_for(params, flags=0):
+    """Allowed |delta steps| per ray: the fixed-step integrators on the strict / hybrid arithmetic must take exactly the
+    reference's number of steps (a ray that does not counts as bad, i.e. against the chaotic-ray allowance); RK45's step
+    controller and the opt-in fast arithmetic may move a step boundary by one or two."""
+    return 2 if (params.integrator == capi.RK45 or (flags & capi.FLAG_FAST_MATH)) else 0
+
+
+def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False, steps_slack=2):
     """Per-ray comparison.  Returns dict(n_traced, n_bad, frac_bad, worst) where a ray is 'bad' if any integer
-    output differs, |steps| differs by more than 2, or a float output is off by more than rtol."""
+    output differs, |steps| differs by more than steps_slack, or a float output is off by more than rtol."""
     assert len(got) == len(want)
     untouched = want["steps"] == -1
     assert (got["steps"][untouched] == -1).all(), "a never-initialised ray was modified"
@@ -48,7 +56,8 @@ def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False):
     bad = np.zeros(len(got), dtype=bool)
     for f in INT_FIELDS:
         bad |= live & (got[f] != want[f])
-    bad |= live & (np.abs(np.abs(got["steps"].astype(np.int64)) - np.abs(want["steps"].astype(np.int64))) > 2)
+    dsteps = np.abs(np.abs(got["steps"].astype(np.int64)) - np.abs(want["steps"].astype(np.int64)))
+    bad |= live & (dsteps > steps_slack)
     bad |= live & (np.sign(got["steps"]) != np.sign(want["steps"]))
     worst = 0.0
     fields = FLOAT_FIELDS + (("redshift",) if check_redshift else ())
@@ -69,8 +78,13 @@ def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False):
         if ok.any():
             worst = max(worst, float(err[ok].max()))
     n_live = int(live.sum())
+    int_bad = np.zeros(len(got), dtype=bool)
+    for f in INT_FIELDS:
+        int_bad |= live & (got[f] != want[f])
+    term_bad = live & (terminal_bits(got["status"]) != terminal_bits(want["status"]))
     return {"n_traced": n_live, "n_bad": int(bad.sum()), "frac_bad": float(bad.sum()) / max(n_live, 1), "worst_ok": worst,
-            "bad_index": np.flatnonzero(bad)}
+            "n_steps_differ": int((live & (dsteps > 0)).sum()), "n_int_fields_differ": int(int_bad.sum()),
+            "frac_terminal_status_differs": float(term_bad.sum()) / max(n_live, 1), "bad_index": np.flatnonzero(bad)}
 
 
 def compare_bins(got, want, rtol=BIN_RTOL, slack=BIN_COUNT_SLACK):
@@ -103,8 +117,47 @@ def noise_envelope_frac(params, init, rtol):
     return compare_rays(out, base, rtol=rtol)["frac_bad"]
 
 
-def allowed_bad_frac(params, init, rtol):
-    return CHAOTIC_FRAC + 3 * noise_envelope_frac(params, init, rtol)
+MAX_BAD_FRAC = 0.05
+
+
+def is_unconverged_endpoint(params):
+    """RK45 + FlatPlaneDestination: the destination has no step_limit(), so the adaptive step overshoots the plane by a
+    rounding-dependent amount and the end POSITION of every ray is ill-conditioned in the reference itself (12 % of its rays
+    move by more than 1e-7 under a 1-ulp change of Q, tests/test_oracle_sensitivity.py)."""
+    return params.integrator == capi.RK45 and params.stop_kind == capi.STOP_FLATPLANE
+
+
+def allowed_bad_frac(params, init, rtol, envelope=None):
+    """1 % (photon-sphere rays) + 3 x the reference's own 1-ulp noise envelope for this run, never more than MAX_BAD_FRAC = 5 %;
+    the one run whose end points are not converged (is_unconverged_endpoint) keeps the uncapped envelope bar for positions and
+    is held to >= 99 % agreement of the terminal status instead (test_trace_vs_golden)."""
+    env = noise_envelope_frac(params, init, rtol) if envelope is None else envelope
+    bar = CHAOTIC_FRAC + 3 * env
+    return bar if is_unconverged_endpoint(params) else min(bar, MAX_BAD_FRAC)
+
+
+# ---- measured margins: every comparison that goes through record_margin ends up in gpurun_out/parity_margins.json (copied to
+# profiles/ per round), so that how close the HIP path runs to each bar is on record, not just pass / fail
+_MARGINS = []
+
+
+def record_margin(test, case, res, allowed=None, envelope=None, **extra):
+    row = {"test": test, "case": case, "n_traced": res["n_traced"], "n_bad": res["n_bad"], "frac_bad": res["frac_bad"], "worst_ok": res["worst_ok"],
+           "n_steps_differ": res.get("n_steps_differ"), "n_int_fields_differ": res.get("n_int_fields_differ"),
+           "frac_terminal_status_differs": res.get("frac_terminal_status_differs"), "allowed_bad_frac": allowed, "noise_envelope_frac": envelope}
+    row.update(extra)
+    _MARGINS.append(row)
+    return row
+
+
+def dump_margins(path):
+    import json
+    import os
+    if not _MARGINS:
+        return
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump({"what": "measured per-ray parity margins of the HIP path against the reference fixtures / the oracle (tests/parity.py)", "rows": _MARGINS}, f, indent=1)
 
 
 def knife_edge_mask(init, imageplane):

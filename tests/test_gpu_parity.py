@@ -42,16 +42,25 @@ def test_trace_vs_golden(krlib, case_name, run, flags):
     out, st = hip_pipeline(case, params, g["init"], flags)
     want = g[f"final__{run}"]
     rtol = parity.rtol_for(params)
+    slack = parity.steps_slack_for(params, flags)
+    mode = {0: "strict", capi.FLAG_FAST_MATH: "fastmath", capi.FLAG_HYBRID: "hybrid"}[flags]
+    envelope = parity.noise_envelope_frac(params, g["init"], rtol)
+    allowed = parity.allowed_bad_frac(params, g["init"], rtol, envelope=envelope)
     if flags & capi.FLAG_FAST_MATH:
         # same tolerances, knife-edge column excluded (parity.knife_edge_mask); step totals are then not comparable
         ke = parity.knife_edge_mask(g["init"], gc.is_imageplane(case))
-        res = parity.compare_rays(parity.drop_rays(out, ke), parity.drop_rays(want, ke), rtol=rtol, check_redshift=True)
+        res = parity.compare_rays(parity.drop_rays(out, ke), parity.drop_rays(want, ke), rtol=rtol, check_redshift=True, steps_slack=slack)
+        parity.record_margin("test_trace_vs_golden", f"{case_name}-{run}-{mode}", res, allowed, envelope)
         assert res["n_traced"] > 0
-        assert res["frac_bad"] <= parity.allowed_bad_frac(params, g["init"], rtol), res
+        assert res["frac_bad"] <= allowed, res
         return
-    res = parity.compare_rays(out, want, rtol=rtol, check_redshift=True)
+    res = parity.compare_rays(out, want, rtol=rtol, check_redshift=True, steps_slack=slack)
+    parity.record_margin("test_trace_vs_golden", f"{case_name}-{run}-{mode}", res, allowed, envelope)
     assert res["n_traced"] > 0
-    assert res["frac_bad"] <= parity.allowed_bad_frac(params, g["init"], rtol), res
+    assert res["frac_bad"] <= allowed, res
+    if parity.is_unconverged_endpoint(params):
+        # end positions are ill-conditioned in the reference itself; what a ray DID (hit the plane / escaped / fell in) is not
+        assert res["frac_terminal_status_differs"] <= 0.01, res
     # the kernel's own step counter agrees with the per-ray records it wrote
     live = out["steps"] != -1
     assert st["steps_total"] == int((np.abs(out["steps"][live].astype(np.int64)) - np.abs(g["init"]["steps"][live].astype(np.int64))).sum())
@@ -273,7 +282,8 @@ def test_perf_test_grid_vs_oracle(krlib, method, flags):
     if flags & capi.FLAG_FAST_MATH:
         ke = parity.knife_edge_mask(init, False)
         out, want = parity.drop_rays(out, ke), parity.drop_rays(want, ke)
-    res = parity.compare_rays(out, want, rtol=parity.rtol_for(p), check_redshift=True)
+    res = parity.compare_rays(out, want, rtol=parity.rtol_for(p), check_redshift=True, steps_slack=parity.steps_slack_for(p, flags))
+    parity.record_margin("test_perf_test_grid_vs_oracle", f"ps_h10_5167-{['euler', 'rk4', 'rk45'][method]}-flags{flags}", res, parity.CHAOTIC_FRAC)
     assert res["frac_bad"] <= parity.CHAOTIC_FRAC, res
     bins = gc.emis_bins(spec, nr=30)
     assert parity.compare_bins(api.reduce_emissivity(bins, out), oracle_reduce_emissivity(bins, want)) == []
@@ -535,3 +545,30 @@ def test_fused_image_pipeline_ends_equal_the_separate_passes(krlib):
     assert p0[-1] > 1000 and p0[-1] == p1[-1]
     np.testing.assert_array_equal(p0[:64 * 64], p1[:64 * 64])
     np.testing.assert_allclose(p0, p1, rtol=1e-12)
+
+
+def test_fused_init_with_keplerian_V_on_a_shard_equals_the_unsharded_source(krlib):
+    """V = -1 makes redshift_start use the orbital velocity at rays[0] of the WHOLE source for every ray (raytracer.cpp:389-393).
+    A strided shard (first = 1, stride = 2: what rank 1 of 2 generates) must use that same velocity, not its own first ray's."""
+    lib, vp = krlib, C.c_void_p
+    spec = ol.pointsource_spec([0.0, 6.0, np.pi / 2 - 1e-3, 0.3], -1.0, gc.SPIN, 0.05, 0.05, cosalpha0=-0.995, cosalphamax=0.995, beta0=-np.pi, betamax=np.pi)
+    n = lib.kr_pointsource_count(C.byref(spec), None, None)
+    full = np.zeros(n, dtype=capi.RAY_F64)
+    d = vp()
+    capi.check(lib, lib.kr_malloc(C.byref(d), n * 144), "malloc")
+    try:
+        capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(spec), 0, 1, -1.0, 0, 0, d, n, None), "init_emit")
+        capi.check(lib, lib.kr_memcpy_d2h(full.ctypes.data_as(vp), d, n * 144), "d2h")
+        # the separate passes on the whole source are the reference semantics
+        sep = api.pointsource_init(spec)
+        api.redshift_start(gc.SPIN, -1.0, 0, 0, sep)
+        assert ol.rays_equal_bitwise(full, sep) == []
+        m = (n - 1 + 1) // 2
+        shard = np.zeros(m, dtype=capi.RAY_F64)
+        capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(spec), 1, 2, -1.0, 0, 0, d, m, None), "init_emit shard")
+        capi.check(lib, lib.kr_memcpy_d2h(shard.ctypes.data_as(vp), d, m * 144), "d2h")
+        assert ol.rays_equal_bitwise(shard, full[1::2][:m]) == []
+        live = shard["steps"] == 0
+        assert live.sum() > 100 and np.ptp(shard["emit"][live]) > 0
+    finally:
+        lib.kr_free(d)
