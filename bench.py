@@ -36,17 +36,39 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6                   # MI355X vector fp64: 256 CU x 
 HBM_PEAK_GBS = 8000.0
 
 
-def make_spec(capi, d, rank=0, world=1, refine=1):
+def make_spec(capi, d, rank=0, world=1, refine=1, strong=False):
     """PointSource spec.  Base grid: spacing d in cos(alpha) and d*pi/0.995 in beta (same point count on both axes).
-    world > 1: rank `rank` owns rows rank, rank+world, ... of the grid refined world-fold in cos(alpha).
+    world > 1, weak scaling: rank `rank` owns rows rank, rank+world, ... of the grid refined world-fold in cos(alpha).
+    world > 1, strong=True: the rows rank, rank+world, ... of the BASE grid itself (fixed total work).
     refine > 1 (with world = 1): that whole refined grid, used for the flux normalisation."""
     s = capi.PointSourceSpec()
     for i in range(4):
         s.pos[i] = SOURCE[i]
     s.V, s.spin, s.tol, s.E = 0.0, SPIN, 100.0, 1.0
-    s.cosalpha0, s.cosalphamax, s.dcosalpha = -0.995 + rank * (d / world), 0.995, d / refine
+    if strong:
+        s.cosalpha0, s.cosalphamax, s.dcosalpha = -0.995 + rank * d, 0.995, d * world
+    else:
+        s.cosalpha0, s.cosalphamax, s.dcosalpha = -0.995 + rank * (d / world), 0.995, d / refine
     s.beta0, s.betamax, s.dbeta = -math.pi, math.pi, d * math.pi / 0.995
     return s
+
+
+def image_column_shard(nx, ny, rank, world, run_cols=1):
+    """Pixel-column-cyclic shard of an nx x ny ray grid stored column after column (ray = i * ny + j): rank r owns the runs of
+    `run_cols` ray columns number r, r + world, ...  Returns (first, stride, run, count) for kr_imageplane_init_emit_runs_dev_f64,
+    whose slot k holds source ray first + (k // run) * stride + k % run."""
+    run = run_cols * ny
+    n_runs = -(-nx // run_cols)
+    mine = range(rank, n_runs, world)
+    count = sum(min(run_cols, nx - b * run_cols) for b in mine) * ny
+    return rank * run, world * run, run, count
+
+
+def image_shard_indices(nx, ny, rank, world, run_cols=1):
+    """The source-ray index of every slot of that shard (what the kernel computes; used by the CPU tests)."""
+    first, stride, run, count = image_column_shard(nx, ny, rank, world, run_cols)
+    k = np.arange(count, dtype=np.int64)
+    return first + (k // run) * stride + k % run
 
 
 def grid_spacing_for(rays):
@@ -160,9 +182,10 @@ class EmissivityWorkload:
         self.lib, self.capi, self.api = lib, capi, api
         self.method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[args.integrator]
         self.d = grid_spacing_for(args.rays or 1e7)
-        self.spec = make_spec(capi, self.d, rank, world)
+        strong = args.scaling == "strong"
+        self.spec = make_spec(capi, self.d, rank, world, strong=strong)
         self.n, self.n_ca, self.n_b = api.pointsource_count(self.spec)
-        full = make_spec(capi, self.d, refine=world)     # the global grid, for the flux normalisation
+        full = make_spec(capi, self.d, refine=1 if strong else world)     # the global grid, for the flux normalisation
         n_primary = int(((full.cosalphamax - full.cosalpha0) / full.dcosalpha) * ((full.betamax - full.beta0) / full.dbeta))
         self.bins = emis_bins(capi, lib.kr_kerr_isco(SPIN, 1), n_primary)
         self.p = capi.default_params(SPIN)
@@ -173,7 +196,8 @@ class EmissivityWorkload:
         self.fused = not args.separate_passes
         self.pipeline = ("[pointsource_init+redshift_start]+trace+[range_phi+redshift+emissivity_histogram] ([..] = one fused pass each)" if self.fused
                          else "pointsource_init+redshift_start+trace+range_phi+redshift+emissivity_histogram")
-        self.sharding = f"row-cyclic over {world} rank(s)"
+        self.sharding = f"row-cyclic over {world} rank(s), " + ("fixed global grid (strong scaling)" if strong else "grid refined with the rank count (weak scaling)")
+        self.scaling = args.scaling
 
     def step(self, d_rays, d_res, stream):
         lib, capi, vp = self.lib, self.capi, C.c_void_p
@@ -203,15 +227,29 @@ class ImagePlaneWorkload:
     def __init__(self, args, lib, capi, api, rank, world):
         self.lib, self.capi, self.api = lib, capi, api
         self.method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[args.integrator]
-        N = int(round(math.sqrt(args.rays))) - 1 if args.rays else 4096
+        N1 = int(round(math.sqrt(args.rays))) - 1 if args.rays else 4096
+        # strong scaling: the N1 x N1 image itself is divided among the ranks; weak: the grid grows so that every rank keeps (N1+1)^2 rays
+        strong = args.scaling == "strong"
+        N = N1 if (strong or world == 1) else int(round(math.sqrt(world) * (N1 + 1))) - 1
         s = capi.ImagePlaneSpec()
         s.dist, s.inc_deg, s.x0, s.xmax, s.y0, s.ymax = 10000.0, 80.0, -30.0, 30.0, -30.0, 30.0
         s.dx = s.dy = 60.0 / N
         s.spin, s.phi0, s.precision = SPIN, 0.0, 100.0
         self.spec, self.N = s, N
         total, nx, ny = api.imageplane_count(s)
-        self.total, self.first, self.stride = total, rank, world
-        self.n = (total - rank + world - 1) // world
+        self.total, self.nx, self.ny, self.rank, self.world = total, nx, ny, rank, world
+        self.exchange = args.image_exchange if world > 1 else "none"
+        if args.image_exchange == "gather":
+            # pixel-column-cyclic: rank r owns the ray columns (= pixel columns, img_dx = dx) r, r + world, ...: disjoint pixel sets,
+            # neighbouring columns cost the same -> balanced; the planes are gathered on rank 0, nothing is summed
+            self.first, self.stride, self.run, self.n = image_column_shard(nx, ny, rank, world)
+            self.sharding = f"pixel-column-cyclic over {world} rank(s) (disjoint pixel sets; planes gathered on rank 0 over the direct xGMI links)"
+        else:
+            self.first, self.stride, self.run = rank, world, 1
+            self.n = (total - rank + world - 1) // world
+            self.sharding = f"ray-cyclic over {world} rank(s) (planes all-reduced)"
+        self.sharding += ", fixed image (strong scaling)" if strong else ", image grown with the rank count (weak scaling)"
+        self.scaling = args.scaling
         b = capi.ImageBins()
         b.x0, b.y0, b.img_dx, b.img_dy = s.x0, s.y0, 60.0 / N, 60.0 / N
         b.r_isco, b.r_disc = lib.kr_kerr_isco(SPIN, 1), 30.0
@@ -227,16 +265,17 @@ class ImagePlaneWorkload:
         self.fused = not args.separate_passes
         self.pipeline = ("[imageplane_init+redshift_start]+trace+[redshift+range_phi+image_planes] ([..] = one fused pass each)" if self.fused
                          else "imageplane_init+redshift_start+trace+redshift+range_phi+image_planes")
-        self.sharding = f"ray-cyclic over {world} rank(s)"
 
     def step(self, d_rays, d_res, stream):
         lib, capi, vp = self.lib, self.capi, C.c_void_p
         n = self.n
         if self.fused:
-            capi.check(lib, lib.kr_imageplane_init_emit_dev_f64(C.byref(self.spec), self.first, self.stride, 0.0, 1, 0, vp(d_rays), n, vp(stream)), "init_emit")
+            capi.check(lib, lib.kr_imageplane_init_emit_runs_dev_f64(C.byref(self.spec), self.first, self.stride, self.run, 0.0, 1, 0, vp(d_rays), n, vp(stream)), "init_emit")
             st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
             capi.check(lib, lib.kr_post_image_dev_f64(-SPIN, -1.0, 1, 0, 0, -math.pi, math.pi, C.byref(self.bins), vp(d_rays), n, vp(d_res), vp(stream)), "post")
             return st
+        if self.run != 1:
+            raise SystemExit("--separate-passes supports the ray-cyclic shards only (use --image-exchange allreduce)")
         capi.check(lib, lib.kr_imageplane_init_strided_dev_f64(C.byref(self.spec), self.first, self.stride, vp(d_rays), n, vp(stream)), "init")
         capi.check(lib, lib.kr_redshift_start_dev_f64(-SPIN, 0.0, 1, 0, vp(d_rays), n, vp(stream)), "redshift_start")
         st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
@@ -244,6 +283,31 @@ class ImagePlaneWorkload:
         capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(d_rays), n, vp(stream)), "range_phi")
         capi.check(lib, lib.kr_reduce_image_dev_f64(C.byref(self.bins), vp(d_rays), n, vp(d_res), vp(stream)), "reduce")
         return st
+
+    def exchange_planes(self, res, dist):
+        """The image pipeline's one exchange.  all-reduce: every rank ends with the summed planes (0.94 GB through the ring at 4096^2).
+        gather: the ranks own disjoint pixel columns, so rank 0 just collects them -- (world-1)/world of the planes arrive over its
+        7 direct xGMI links in parallel, nothing is added; the other ranks' `res` keeps their own columns only."""
+        import torch
+        if self.exchange == "allreduce":
+            dist.all_reduce(res, op=dist.ReduceOp.SUM)
+            return
+        N, W, r = self.N, self.world, self.rank
+        cols = -(-N // W)                                    # columns per rank, padded to the same size for the collective
+        planes = res[:7 * N * N].view(7, N, N)
+        mine = torch.zeros(7 * cols * N + 1, dtype=res.dtype, device=res.device)
+        own = planes[:, r::W, :]
+        mine[:7 * cols * N].view(7, cols, N)[:, :own.shape[1], :] = own
+        mine[-1] = res[-1]                                   # this rank's disc-ray count
+        parts = [torch.empty_like(mine) for _ in range(W)] if r == 0 else None
+        dist.gather(mine, parts, dst=0)
+        if r == 0:
+            count = 0.0
+            for q, part in enumerate(parts):
+                nq = len(range(q, N, W))
+                planes[:, q::W, :] = part[:7 * cols * N].view(7, cols, N)[:, :nq, :]
+                count = count + part[-1]
+            res[-1] = count
 
     def summary(self, h):
         return {"disc_hits": float(h[-1]), "lit_pixels": int((h[: self.N * self.N] > 0).sum())}
@@ -258,7 +322,8 @@ class ReturnRadiationWorkload:
     def __init__(self, args, lib, capi, api, rank, world):
         self.lib, self.capi, self.api = lib, capi, api
         self.method = {"euler": capi.EULER, "rk4": capi.RK4, "rk45": capi.RK45}[args.integrator]
-        self.nr = args.radii
+        self.nr = args.radii * (world if args.scaling == "weak" else 1)      # weak: every rank keeps args.radii source radii
+        self.scaling = args.scaling
         rays = args.rays or 1e6
         self.r_isco = lib.kr_kerr_isco(SPIN, 1)
         dr = math.exp(math.log(R_DISC / self.r_isco) / self.nr)
@@ -283,7 +348,7 @@ class ReturnRadiationWorkload:
                          f"r_max=1.1*r_esc, per-radius relaunch (BASELINE configs[4])")
         self.pipeline = (f"per radius: [pointsource_init+redshift_start]+trace+range_phi+return_classification; radii round-robin over {self.nstreams} stream(s), "
                          "longest launches first, one counter read-back at the end")
-        self.sharding = f"radii cyclic over {world} rank(s)"
+        self.sharding = f"radii cyclic over {world} rank(s), " + ("fixed set of radii (strong scaling)" if args.scaling == "strong" else "radii added with the rank count (weak scaling)")
 
     def step(self, d_rays, d_res, stream):
         """Radii go round-robin over self.nstreams HIP streams (each with its own ray buffer), the radii whose launches have the
@@ -354,6 +419,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="emissivity", choices=["emissivity", "imageplane", "return_radiation"])
     ap.add_argument("--radii", type=int, default=100, help="return_radiation: number of source radii")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = per-GPU work fixed (the grid / image / set of radii grows with N); strong = the N = 1 problem divided among the ranks")
+    ap.add_argument("--image-exchange", default="gather", choices=["gather", "allreduce"],
+                    help="imageplane, N > 1: gather = pixel-column-cyclic shards, planes collected on rank 0; allreduce = ray-cyclic shards, planes summed everywhere")
+    ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: run the exchange on the compute stream instead of beside the next pass")
     ap.add_argument("--streams", type=int, default=4, help="return_radiation: HIP streams the per-radius launches are spread over (1 = serial relaunch)")
     ap.add_argument("--rays", type=float, default=0, help="rays per GPU (default: 1e7 emissivity = BASELINE configs[1]; 4097^2 imageplane = configs[3])")
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
@@ -400,15 +470,40 @@ def main():
     wl.p.flags = (wl.p.flags & ~mode_mask) | mode_flags[args.arithmetic]
     n = wl.n
     rays = torch.empty(n * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda")
-    res = torch.zeros(wl.result_words, dtype=torch.float64, device="cuda")
+    # the result (histogram / planes / fraction table) is double-buffered: the exchange of pass k runs on a stream of its own while
+    # pass k+1 initialises and traces its rays into the other buffer
+    overlap = dist is not None and not args.no_overlap_exchange
+    results = [torch.zeros(wl.result_words, dtype=torch.float64, device="cuda") for _ in range(2 if overlap else 1)]
+    comm_stream = torch.cuda.Stream() if overlap else None
+    exchanged = [torch.cuda.Event() for _ in results]
+    state = {"k": 0, "last": results[0]}
     stream = torch.cuda.current_stream().cuda_stream
-    d_rays, d_res = rays.data_ptr(), res.data_ptr()
+    d_rays = rays.data_ptr()
+
+    def exchange(res):
+        if hasattr(wl, "exchange_planes"):
+            wl.exchange_planes(res, dist)
+        else:
+            dist.all_reduce(res, op=dist.ReduceOp.SUM)      # RCCL over xGMI: the path's one exchange
 
     def one_step():
+        cur = torch.cuda.current_stream()
+        slot = state["k"] % len(results)
+        res = results[slot]
+        state["k"] += 1
+        state["last"] = res
+        if overlap:
+            cur.wait_event(exchanged[slot])                 # the exchange that last read this buffer has finished
         res.zero_()
-        st = wl.step(d_rays, d_res, stream)
+        st = wl.step(d_rays, res.data_ptr(), stream)
         if dist is not None:
-            dist.all_reduce(res, op=dist.ReduceOp.SUM)      # RCCL over xGMI: the path's one exchange
+            if overlap:
+                comm_stream.wait_stream(cur)
+                with torch.cuda.stream(comm_stream):
+                    exchange(res)
+                    exchanged[slot].record(comm_stream)
+            else:
+                exchange(res)
         return st
 
     def fence():
@@ -437,7 +532,7 @@ def main():
     else:
         traced_all, steps_all = traced, steps_total
 
-    h = res.cpu().numpy()
+    h = state["last"].cpu().numpy()
     # the other two arithmetic modes on the same workload, reported beside the headline
     others = None
     if world == 1 and not args.no_fast_math_extra:
@@ -474,9 +569,10 @@ def main():
         out = {
             "metric": "rays_per_sec", "value": traced_all * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.describe, "rays_per_gpu": int(traced), "allocated_rays_per_gpu": int(n), "rays_total": int(traced_all),
-                       "integrator": args.integrator, "arithmetic": ARITHMETIC_NOTE[args.arithmetic], "rays_on_strict_side_launch": int(stats_last.get("rays_strict_side", 0)), "pipeline": wl.pipeline + ("+rccl_allreduce" if world > 1 else ""), "sharding": wl.sharding},
+                       "integrator": args.integrator, "arithmetic": ARITHMETIC_NOTE[args.arithmetic], "rays_on_strict_side_launch": int(stats_last.get("rays_strict_side", 0)), "pipeline": wl.pipeline + (("+rccl_" + (getattr(wl, "exchange", "allreduce")) + ("(beside the next pass)" if overlap else "")) if dist is not None else ""),
+                       "sharding": wl.sharding},
             "rk_steps_per_sec": steps_all * args.steps / elapsed,
             "rk_steps_per_launch": int(steps_total), "mean_steps_per_ray": steps_total / max(traced, 1),
             "roofline": {"bound": "valu_fp64", "kernel": "kr::trace_kernel<double>", "achieved": achieved_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,

@@ -277,6 +277,11 @@ int kr_pointsource_init_emit_dev_f64(const kr_pointsource* s, int64_t first, int
  * kr_reduce_image_dev_f64 (imageplane_disc_image.cpp:117-161; `spin` as stored by the Raytracer, i.e. negated) */
 int kr_imageplane_init_emit_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d_rays, int64_t count,
                                     void* stream);
+/* the same ctor for shards made of RUNS of rays: slot k receives source ray first + (k / run) * stride + k % run.  With run = (ray columns
+ * per pixel column) * ny, stride = R * run and first = r * run, rank r of R owns whole pixel columns r, r + R, ... of the image: the ranks'
+ * image planes are then disjoint and are GATHERED, not summed (bench.py --image-exchange gather).  run = 1 is the plain strided form. */
+int kr_imageplane_init_emit_runs_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, int64_t run, double V, int reverse, int projradius, void* d_rays,
+                                         int64_t count, void* stream);
 int kr_post_image_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_image_bins* b, void* d_rays, int64_t n,
                           void* d_planes, void* stream);
 int kr_post_emissivity_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d_rays, int64_t n,

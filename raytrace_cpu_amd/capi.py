@@ -140,6 +140,7 @@ PROTOTYPES = {
     "kr_reduce_emissivity_dev_f64": (_int, [P(EmisBins), _vp, _i64, _vp, _vp]),
     "kr_pointsource_init_emit_dev_f64": (_int, [P(PointSourceSpec), _i64, _i64, _dbl, _int, _int, _vp, _i64, _vp]),
     "kr_imageplane_init_emit_dev_f64": (_int, [P(ImagePlaneSpec), _i64, _i64, _dbl, _int, _int, _vp, _i64, _vp]),
+    "kr_imageplane_init_emit_runs_dev_f64": (_int, [P(ImagePlaneSpec), _i64, _i64, _i64, _dbl, _int, _int, _vp, _i64, _vp]),
     "kr_post_image_dev_f64": (_int, [_dbl, _dbl, _int, _int, _int, _dbl, _dbl, P(ImageBins), _vp, _i64, _vp, _vp]),
     "kr_post_emissivity_dev_f64": (_int, [_dbl, _dbl, _int, _int, _int, _dbl, _dbl, P(EmisBins), _vp, _i64, _vp, _vp]),
     "kr_reduce_image_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(_i64)]),

@@ -27,8 +27,8 @@ int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t firs
 int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st);
 int post_emissivity_dev(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d, int64_t n,
                         void* d_hist, hipStream_t st);
-int imageplane_init_emit_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, double spin, double V, int reverse, int projradius,
-                             hipStream_t st);
+int imageplane_init_emit_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, int64_t run, double spin, double V, int reverse,
+                             int projradius, hipStream_t st);
 int post_image_dev(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_image_bins* b, void* d, int64_t n,
                    void* d_planes, hipStream_t st);
 int pointsource_init_emit_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, double V, int reverse, int projradius, hipStream_t st);
@@ -80,18 +80,25 @@ int with_staged_rays(void* rays, int64_t n, size_t ray_bytes, bool copy_in, bool
     int rc = require_device();
     if (rc != KR_OK) return rc;
     if (n == 0) return body(nullptr);
+    static const bool timing = getenv("KR_TIMING") != nullptr;      // per-call breakdown on stderr (scripts/app_wall.sh)
+    auto t0 = clk::now();
     DeviceBuffer buf;
     rc = buf.alloc((size_t) n * ray_bytes);
     if (rc != KR_OK) return rc;
-    auto t0 = clk::now();
+    const double t_alloc = ms_since(t0);
+    t0 = clk::now();
     if (copy_in) KR_HIP(hipMemcpy(buf.p, rays, (size_t) n * ray_bytes, hipMemcpyHostToDevice));
     const double h2d = ms_since(t0);
+    t0 = clk::now();
     rc = body(buf.p);
     if (rc != KR_OK) return rc;
     KR_HIP(hipDeviceSynchronize());
+    const double t_body = ms_since(t0);
     t0 = clk::now();
     if (copy_out) KR_HIP(hipMemcpy(rays, buf.p, (size_t) n * ray_bytes, hipMemcpyDeviceToHost));
-    if (stats) { stats->h2d_ms = h2d; stats->d2h_ms = ms_since(t0); }
+    const double d2h = ms_since(t0);
+    if (stats) { stats->h2d_ms = h2d; stats->d2h_ms = d2h; }
+    if (timing) std::fprintf(stderr, "kr_timing: staged call n=%lld alloc %.1f ms h2d %.1f ms kernels %.1f ms d2h %.1f ms\n", (long long) n, t_alloc, h2d, t_body, d2h);
     return KR_OK;
 }
 
@@ -352,7 +359,14 @@ int kr_imageplane_init_emit_dev_f64(const kr_imageplane* s, int64_t first, int64
 {
     if (!s) { set_error("kr_imageplane_init_emit: null spec"); return KR_EINVAL; }
     int rc = require_device();
-    return rc != KR_OK ? rc : imageplane_init_emit_dev(s, d, count, first, stride, -1 * s->spin, V, reverse, projradius, (hipStream_t) st);
+    return rc != KR_OK ? rc : imageplane_init_emit_dev(s, d, count, first, stride, 1, -1 * s->spin, V, reverse, projradius, (hipStream_t) st);
+}
+int kr_imageplane_init_emit_runs_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, int64_t run, double V, int reverse, int projradius, void* d,
+                                         int64_t count, void* st)
+{
+    if (!s) { set_error("kr_imageplane_init_emit_runs: null spec"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : imageplane_init_emit_dev(s, d, count, first, stride, run, -1 * s->spin, V, reverse, projradius, (hipStream_t) st);
 }
 int kr_post_image_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_image_bins* b, void* d, int64_t n,
                           void* d_planes, void* st)

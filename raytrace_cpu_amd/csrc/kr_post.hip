@@ -341,8 +341,8 @@ imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane
 // ---- fused prologue of the image pipeline: ImagePlane ctor + redshift_start(V, reverse, projradius) in one pass; `spin` is the
 //      Raytracer member (the ImagePlane has negated it), as for kr_redshift_start_dev_f64 -----------------------------------
 __global__ void __launch_bounds__(kBlock)
-imageplane_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny, long long first, long long stride, double spin,
-                            double V, int reverse, int projradius)
+imageplane_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny, long long first, long long stride, long long run,
+                            double spin, double V, int reverse, int projradius)
 {
     const long long n_grid = (long long) Nx * Ny;
     const double a = -1 * s.spin;
@@ -353,7 +353,9 @@ imageplane_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_image
         V = keplerian_V(am, r0.r, r0.theta, projradius != 0);
     }
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
-        kr_ray_f64 ray = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, first + slot * stride);
+        // slot -> source ray: runs of `run` consecutive rays, `stride` apart (run = 1: plain ray-cyclic)
+        const long long src = (run == 1) ? first + slot * stride : first + (slot / run) * stride + (slot % run);
+        kr_ray_f64 ray = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, src);
         ray.emit = emit_value(ray, spin, am, V, reverse);
         rays[slot] = ray;
     }
@@ -668,15 +670,15 @@ int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t firs
     return KR_OK;
 }
 
-int imageplane_init_emit_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, double spin, double V, int reverse, int projradius,
-                             hipStream_t st)
+int imageplane_init_emit_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, int64_t run, double spin, double V, int reverse,
+                             int projradius, hipStream_t st)
 {
     int32_t nx = 0, ny = 0;
     kr_imageplane_count(s, &nx, &ny);
-    if (first < 0 || stride < 1) { set_error("kr_imageplane_init_emit: bad first/stride"); return KR_EINVAL; }
+    if (first < 0 || stride < 1 || run < 1 || run > stride) { set_error("kr_imageplane_init_emit: bad first/stride/run"); return KR_EINVAL; }
     if (n <= 0) return KR_OK;
     hipLaunchKernelGGL(imageplane_init_emit_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nx, ny, (long long) first,
-                       (long long) stride, spin, V, reverse, projradius);
+                       (long long) stride, (long long) run, spin, V, reverse, projradius);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }

@@ -13,6 +13,32 @@
 #define KR_COMPACT_SINCOS 1
 #endif
 
+// Polynomial coefficients as scalar-register operands.  gfx950 has no 64-bit literals: the compiler's default for fma(z, p, C) is
+// v_fmac_f64 with C copied into the destination VGPR pair first -- two v_mov_b32 per coefficient, i.e. three vector instructions
+// per Horner step, ~50 extra VALU instructions per RK4 step of a kernel that is VALU-issue bound.  Passing the constant through
+// an empty asm with an "s" constraint pins it to an SGPR pair (s_mov_b32 x2 on the scalar unit, which runs beside the vector
+// unit) and the step becomes one v_fma_f64 v, v, v, s[..].  Same value, same rounding.
+// MEASURED AND REJECTED (default off): the fast RK4 kernel loses 38 v_mov per step and its 12 spilled VGPRs, but gains 40 spilled
+// SGPRs whose reloads (v_readlane) sit in the step loop: 94.1 ms against 92.7 ms (1e7 rays; profiles/r02_ab_experiments.txt).
+// The blanket alternative -- building without v_fmac_f64 (-target-feature -fmacf64-inst) -- loses the same way (93.2 vs 90.8 ms).
+#ifndef KR_SGPR_COEFFS
+#define KR_SGPR_COEFFS 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && KR_SGPR_COEFFS
+static __device__ __forceinline__ double kr_sconst(double c) { asm volatile("" : "+s"(c)); return c; }
+#define KR_K(x) kr_sconst(x)
+#else
+#define KR_K(x) (x)
+#endif
+#ifndef KR_SGPR_COEFFS_STRICT
+#define KR_SGPR_COEFFS_STRICT 1
+#endif
+#if KR_SGPR_COEFFS_STRICT
+#define KR_KS(x) KR_K(x)          /* the strict-path routines (kr_sincos_general_f64, kr_sincos_small_f64) */
+#else
+#define KR_KS(x) (x)
+#endif
+
 // sin and cos of a polar angle.  theta stays within a few multiples of pi (it is reflected back into [0, pi]
 // after every step and the RK stages move it by a fraction of that), so the general-purpose device sincos
 // (Payne-Hanek capable, ~90 VALU instructions, 4 calls per RK4 step = a third of the step) is replaced by:
@@ -38,9 +64,9 @@
 KR_SC_FN void kr_sincos_small_f64(double x, double& s, double& c)
 {
     const double z = x * x;
-    const double ps = __builtin_fma(z, __builtin_fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01);
+    const double ps = __builtin_fma(z, __builtin_fma(z, KR_KS(-1.98412698412698412698e-04), KR_KS(8.33333333333333333333e-03)), KR_KS(-1.66666666666666666667e-01));
     s = __builtin_fma(x * z, ps, x);
-    const double pc = __builtin_fma(z, -1.38888888888888888889e-03, 4.16666666666666666667e-02);
+    const double pc = __builtin_fma(z, KR_KS(-1.38888888888888888889e-03), KR_KS(4.16666666666666666667e-02));
     c = 1.0 + __builtin_fma(z * z, pc, -0.5 * z);
 }
 
@@ -87,12 +113,12 @@ KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
     const double z = r * r;
     // sin(r + y)
     const double v = z * r;
-    const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                                                                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+    const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, KR_KS(1.58969099521155010221e-10), KR_KS(-2.50507602534068634195e-08)),
+                                                                      KR_KS(2.75573137070700676789e-06)), KR_KS(-1.98412698298579493134e-04)), KR_KS(8.33333333332248946124e-03));
     const double sr = r - ((z * (0.5 * y - v * ps) - y) - v * -1.66666666666666324348e-01);
     // cos(r + y)
-    const double pc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                                                                                          -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double pc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, KR_KS(-1.13596475577881948265e-11), KR_KS(2.08757232129817482790e-09)),
+                                                                                          KR_KS(-2.75573143513906633035e-07)), KR_KS(2.48015872894767294178e-05)), KR_KS(-1.38888888888741095749e-03)), KR_KS(4.16666666666666019037e-02));
     const double ar = __builtin_fabs(r);
     // qx ~ |r|/4 with a short mantissa, so that 1 - qx and z/2 - qx are exact (0 below 0.3, capped at 0.28125)
     const unsigned long long qbits = (__builtin_bit_cast(unsigned long long, ar) - 0x0020000000000000ull) & 0xFFFFFFFF00000000ull;
@@ -128,17 +154,17 @@ KR_SC_FN void kr_sincos_fast_f64(double x, double& s, double& c)
     double r = __builtin_fma(-t, 1.57079632679489655800e+00, x);
     r = __builtin_fma(-t, 6.12323399573676603587e-17, r);
     const double z = r * r;
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double ps = __builtin_fma(z, KR_K(1.58969099521155010221e-10), KR_K(-2.50507602534068634195e-08));
+    ps = __builtin_fma(z, ps, KR_K(2.75573137070700676789e-06));
+    ps = __builtin_fma(z, ps, KR_K(-1.98412698298579493134e-04));
+    ps = __builtin_fma(z, ps, KR_K(8.33333333332248946124e-03));
+    ps = __builtin_fma(z, ps, KR_K(-1.66666666666666324348e-01));
     const double sr = __builtin_fma(r * z, ps, r);
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double pc = __builtin_fma(z, KR_K(-1.13596475577881948265e-11), KR_K(2.08757232129817482790e-09));
+    pc = __builtin_fma(z, pc, KR_K(-2.75573143513906633035e-07));
+    pc = __builtin_fma(z, pc, KR_K(2.48015872894767294178e-05));
+    pc = __builtin_fma(z, pc, KR_K(-1.38888888888741095749e-03));
+    pc = __builtin_fma(z, pc, KR_K(4.16666666666666019037e-02));
     pc = __builtin_fma(z, pc, -0.5);
     const double cr = __builtin_fma(z, pc, 1.0);
     const bool odd = (n & 1) != 0;

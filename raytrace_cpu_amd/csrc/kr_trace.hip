@@ -37,7 +37,13 @@ namespace kr {
 
 namespace {
 
-constexpr int kBlock = 256;          // 4 independent waves per workgroup, no barriers
+constexpr int kBlock = 256;          // classification kernel
+#ifndef KR_TRACE_BLOCK
+#define KR_TRACE_BLOCK 64            // trace kernel: one wave per workgroup -- a wave gives its registers back the moment IT has finished, not when the
+                                     // slowest of four has: main launch 93.1 -> 87.2 ms at 1e7 rays (256: four independent waves per workgroup)
+#endif
+constexpr int kTraceBlock = KR_TRACE_BLOCK;
+constexpr int kWavesPerBlock = kTraceBlock / 64;
 #ifndef KR_REFILL_MIN
 #define KR_REFILL_MIN 1
 #endif
@@ -125,7 +131,7 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 #define KR_HOG_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? 3 : METHOD == KR_RK45 ? 2 : 1, HOG ? KR_HOG_MAX_WAVES : 8)))
 #endif
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(kBlock, kBlock))) KR_HOG_ATTR
+__global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_HOG_ATTR
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
              const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want)
 {
@@ -456,7 +462,7 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     static int occ = 0;
     if (occ == 0) {
         int v = 0;
-        KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, kBlock, 0));
+        KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, kTraceBlock, 0));
         occ = v < 1 ? 1 : v;
     }
     int blocks_per_cu = occ;
@@ -472,12 +478,13 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
         const int v = atoi(e);
         if (v >= 1) want = v;
     }
+    want *= 4 / kWavesPerBlock;                 // `want` counts 256-thread workgroups (= waves per SIMD)
     if (want < blocks_per_cu) blocks_per_cu = want;
     const int64_t resident = (int64_t) cus * blocks_per_cu;
-    const int64_t wanted = (n + kBlock - 1) / kBlock;
+    const int64_t wanted = (n + kTraceBlock - 1) / kTraceBlock;
     int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
     if (la.fixed_grid > 0) grid = la.fixed_grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.n_mode, la.mask, la.mask_want);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTraceBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.n_mode, la.mask, la.mask_want);
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
@@ -534,7 +541,7 @@ int dispatch_split(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim,
     strict_la.n_ptr = split_words + 1;
     strict_la.n_mode = 1;
     const int64_t list_max = std::min<int64_t>(n, kListCap);
-    strict_la.fixed_grid = (int) std::max<int64_t>(1, std::min<int64_t>((list_max + kBlock - 1) / kBlock, ws->cus / 2));
+    strict_la.fixed_grid = (int) std::max<int64_t>(1, std::min<int64_t>((list_max + kTraceBlock - 1) / kTraceBlock, (int64_t) (ws->cus / 2) * (4 / kWavesPerBlock)));
     int rc = launch_f64<false, true>(p, rays, list_max, c, ws->counters + kCounters, ws->cus, stream, 1, strict_la);
     if (rc != KR_OK) return rc;
     KR_HIP(hipEventRecord(ws->ev_strict1, stream));

@@ -15,13 +15,13 @@ for rep in 1 2; do
   timed $NATIVE/kr_emissivity --parfile=$PAR/emissivity_c2.par --outfile=$W/c2_native.dat --timing
 done
 echo "== reference emissivity main() on the class API (host ray array, H2D + D2H), same grid, RK45 as hard-coded there"
-( mkdir -p $W/par $W/run && cp $PAR/emissivity_c2.par $W/par/emissivity.par && cd $W/run && timed $DROPIN/emissivity --outfile=$W/c2_dropin.dat )
+( export KR_TIMING=1; mkdir -p $W/par $W/run && cp $PAR/emissivity_c2.par $W/par/emissivity.par && cd $W/run && timed $DROPIN/emissivity --outfile=$W/c2_dropin.dat )
 for rep in 1 2; do
   echo "== kr_imageplane_disc_image (device-resident), imageplane_c4.par, run $rep"
   timed $NATIVE/kr_imageplane_disc_image --parfile=$PAR/imageplane_c4.par --outfile=$W/c4_native.fits --timing
 done
 echo "== reference imageplane_disc_image main() on the class API, same par"
-timed $DROPIN/imageplane_disc_image --parfile=$PAR/imageplane_c4.par --outfile=$W/c4_dropin.fits
+( export KR_TIMING=1; timed $DROPIN/imageplane_disc_image --parfile=$PAR/imageplane_c4.par --outfile=$W/c4_dropin.fits )
 ls -la $W
 cmp $W/c4_native.fits $W/c4_dropin.fits && echo "c4: native and drop-in FITS files are byte-identical" || echo "c4: files differ (sum order of atomics)"
 } > $OUT/app_wall.txt 2>&1

@@ -118,6 +118,8 @@ def noise_envelope_frac(params, init, rtol):
 
 
 MAX_BAD_FRAC = 0.05
+STRICT_BAD_FRAC = 1e-3      # fixed-step integrators on the strict arithmetic: measured 0 bad rays on every PointSource fixture, 2 of 289 on the
+STRICT_BAD_RAYS = 2.5       # image-plane grid that contains the x = 0 column and the NaN pixel (profiles/r02_parity_margins.json)
 
 
 def is_unconverged_endpoint(params):
@@ -134,6 +136,13 @@ def allowed_bad_frac(params, init, rtol, envelope=None):
     env = noise_envelope_frac(params, init, rtol) if envelope is None else envelope
     bar = CHAOTIC_FRAC + 3 * env
     return bar if is_unconverged_endpoint(params) else min(bar, MAX_BAD_FRAC)
+
+
+def allowed_bad_frac_strict(params, n_traced):
+    """Euler / RK4 with flags = 0: the only difference from the CPU is sin / cos in the last place, and the fixtures show what that
+    costs -- nothing.  The bar is therefore fixed, not derived from the noise envelope: 1e-3 of the rays, or 2 rays on a small grid."""
+    assert params.integrator != capi.RK45
+    return max(STRICT_BAD_FRAC, STRICT_BAD_RAYS / max(n_traced, 1))
 
 
 # ---- measured margins: every comparison that goes through record_margin ends up in gpurun_out/parity_margins.json (copied to

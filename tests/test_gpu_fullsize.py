@@ -222,7 +222,7 @@ def test_imageplane_4097_full_size_properties(krlib):
 def test_return_radiation_full_size_properties(krlib):
     """BASELINE configs[4]: 100 source radii x ~1e6 rays, Euler, one launch per radius spread over 4 streams (bench.py's
     ReturnRadiationWorkload, the driver that mirrors src/return_radiation/disc_source_photonfrac_r.cpp:74-135).
-      * per radius: return + escape + lost == ray_count (every weighted ray is classified exactly once), fractions in [0, 1];
+      * per radius: return + escape + lost <= ray_count (the classes are disjoint), and within 5 % of it;
       * the overlapped launches (4 streams, async tickets) give the table of the serial relaunch loop;
       * one radius split into 3 ray-cyclic shards adds up to that radius's row;
       * a sample of one radius's rays equals the oracle's trace of the same records."""
@@ -232,7 +232,7 @@ def test_return_radiation_full_size_properties(krlib):
 
     import bench
     lib = krlib
-    args = types.SimpleNamespace(integrator="euler", radii=100, rays=1e6, streams=4)
+    args = types.SimpleNamespace(integrator="euler", radii=100, rays=1e6, streams=4, scaling="weak")
     wl = bench.ReturnRadiationWorkload(args, lib, capi, api, 0, 1)
     wl.p.flags = capi.FLAG_HYBRID
     n = wl.n
@@ -245,10 +245,14 @@ def test_return_radiation_full_size_properties(krlib):
     assert st["rays_traced"] > 9.9e7 and st["steps_total"] > 1e10
     tot, ret, esc, lost = table.T
     assert (tot > 1e5).all()
-    np.testing.assert_allclose(ret + esc + lost, tot, rtol=1e-12)
+    # the three classes do not cover every ray (disc_source_photonfrac_r.cpp:104-126: hits next to the source itself and rays
+    # between r_disc and r_esc are counted in ray_count only), but nearly all, and never more than all
+    frac = (ret + esc + lost) / tot
+    assert (frac <= 1 + 1e-12).all() and (frac > 0.95).all(), (frac.min(), frac.max())
+    assert np.ptp(tot) < 1e-6                                                 # same angular grid at every radius (sum order only)
     assert ((ret >= 0) & (esc >= 0) & (lost >= 0)).all() and (ret[0] / tot[0] > esc[0] / tot[0]) and (esc[-1] / tot[-1] > 0.4)
     # serial relaunch loop on one stream: same table
-    args1 = types.SimpleNamespace(integrator="euler", radii=100, rays=1e6, streams=1)
+    args1 = types.SimpleNamespace(integrator="euler", radii=100, rays=1e6, streams=1, scaling="weak")
     wl1 = bench.ReturnRadiationWorkload(args1, lib, capi, api, 0, 1)
     wl1.p.flags = capi.FLAG_HYBRID
     res.zero_()

@@ -55,6 +55,8 @@ def test_trace_vs_golden(krlib, case_name, run, flags):
         assert res["frac_bad"] <= allowed, res
         return
     res = parity.compare_rays(out, want, rtol=rtol, check_redshift=True, steps_slack=slack)
+    if flags == 0 and params.integrator != capi.RK45:
+        allowed = parity.allowed_bad_frac_strict(params, res["n_traced"])          # strict arithmetic, fixed step: a fixed, tight bar
     parity.record_margin("test_trace_vs_golden", f"{case_name}-{run}-{mode}", res, allowed, envelope)
     assert res["n_traced"] > 0
     assert res["frac_bad"] <= allowed, res
@@ -551,7 +553,7 @@ def test_fused_init_with_keplerian_V_on_a_shard_equals_the_unsharded_source(krli
     """V = -1 makes redshift_start use the orbital velocity at rays[0] of the WHOLE source for every ray (raytracer.cpp:389-393).
     A strided shard (first = 1, stride = 2: what rank 1 of 2 generates) must use that same velocity, not its own first ray's."""
     lib, vp = krlib, C.c_void_p
-    spec = ol.pointsource_spec([0.0, 6.0, np.pi / 2 - 1e-3, 0.3], -1.0, gc.SPIN, 0.05, 0.05, cosalpha0=-0.995, cosalphamax=0.995, beta0=-np.pi, betamax=np.pi)
+    spec = ol.pointsource_spec([0.0, 6.0, np.pi / 2 - 1e-3, 0.3], gc.kep_velocity(6.0), gc.SPIN, 0.05, 0.05, cosalpha0=-0.995, cosalphamax=0.995, beta0=-np.pi, betamax=np.pi)
     n = lib.kr_pointsource_count(C.byref(spec), None, None)
     full = np.zeros(n, dtype=capi.RAY_F64)
     d = vp()
@@ -569,6 +571,6 @@ def test_fused_init_with_keplerian_V_on_a_shard_equals_the_unsharded_source(krli
         capi.check(lib, lib.kr_memcpy_d2h(shard.ctypes.data_as(vp), d, m * 144), "d2h")
         assert ol.rays_equal_bitwise(shard, full[1::2][:m]) == []
         live = shard["steps"] == 0
-        assert live.sum() > 100 and np.ptp(shard["emit"][live]) > 0
+        assert live.sum() > 100 and np.isfinite(shard["emit"][live]).all() and np.ptp(shard["emit"][live]) > 0
     finally:
         lib.kr_free(d)

@@ -162,3 +162,100 @@ def test_ray_cyclic_image_shards_reduce_to_the_global_planes():
     assert res[0][1][-1] == full[-1] > 0                                   # disc rays
     np.testing.assert_allclose(res[0][1], full, rtol=1e-12)
     assert res[0][2] + res[1][2] == st_full["rays_traced"]
+
+
+# ---- image plane, pixel-column-cyclic shards + gather (bench.py --image-exchange gather, the default) ---------------------
+IMG_G = 24          # image = ray grid spacing (img_dx = dx), as in the application: one ray column per pixel column
+
+
+def _image_planes_g(rays, img):
+    o = ol.oracle()
+    spin = bench.SPIN
+    p = capi.default_params(-spin)
+    p.integrator, p.r_max = capi.RK4, 11000.0
+    out, st = ol.oracle_trace(p, rays, nthreads=2)
+    o.kro_redshift_f64(-spin, -1.0, 1, 0, 0, ol.ptr(out), len(out))
+    o.kro_range_phi_f64(-np.pi, np.pi, ol.ptr(out), len(out))
+    b = capi.ImageBins()
+    b.x0, b.y0, b.img_dx, b.img_dy = -30.0, -30.0, 60.0 / img, 60.0 / img
+    b.r_isco, b.r_disc = o.kro_kerr_isco(spin, 1), 30.0
+    b.q1, b.rb1, b.q2, b.rb2, b.q3 = 3.0, 4.0, 3.0, 10.0, 3.0
+    b.img_nx, b.img_ny, b.flip_image, b.pad = img, img, 1, 0
+    npix = img * img
+    n = np.zeros(npix, dtype=np.int32)
+    planes = [np.zeros(npix) for _ in range(6)]
+    dc = C.c_int64()
+    o.kro_reduce_image_f64(C.byref(b), ol.ptr(out), len(out), ol.ptr(n), *[ol.ptr(x) for x in planes], C.byref(dc))
+    return np.concatenate([n.astype(np.float64)] + planes + [[float(dc.value)]]), st
+
+
+def _image_init_g():
+    spec = ol.imageplane_spec(10000.0, 80.0, -30.0, 30.0, 60.0 / IMG_G, -30.0, 30.0, 60.0 / IMG_G, bench.SPIN)
+    rays = ol.oracle_imageplane(spec)
+    ol.oracle().kro_redshift_start_f64(-bench.SPIN, 0.0, 1, 0, ol.ptr(rays), len(rays))
+    return rays
+
+
+def _image_gather_worker(rank, world, port, q):
+    import types
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nx = ny = IMG_G + 1
+    idx = bench.image_shard_indices(nx, ny, rank, world)           # the slots kr_imageplane_init_emit_runs_dev_f64 fills on this rank
+    mine = _image_init_g()[idx].copy()
+    h, st = _image_planes_g(mine, IMG_G)
+    t = torch.from_numpy(h.copy())
+    fake = types.SimpleNamespace(N=IMG_G, world=world, rank=rank, exchange="gather")
+    bench.ImagePlaneWorkload.exchange_planes(fake, t, dist)        # the bench's own exchange code, over gloo
+    q.put((rank, t.numpy().copy(), st["rays_traced"], idx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pixel_column_cyclic_image_shards_gather_to_the_global_planes(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_image_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    init = _image_init_g()
+    full, st_full = _image_planes_g(init, IMG_G)
+    # the shards partition the ray grid ...
+    allidx = np.sort(np.concatenate([r[3] for r in res]))
+    np.testing.assert_array_equal(allidx, np.arange((IMG_G + 1) ** 2))
+    assert sum(r[2] for r in res) == st_full["rays_traced"]
+    # ... own disjoint pixel columns, and rank 0 holds the single-process planes after the gather: no sum was needed, so even
+    # the floating-point planes are bit-identical as long as each pixel's rays were added in the same order (one rank, one pixel)
+    got = res[0][1]
+    npix = IMG_G * IMG_G
+    np.testing.assert_array_equal(got[:npix], full[:npix])
+    assert got[-1] == full[-1] > 0
+    np.testing.assert_allclose(got, full, rtol=1e-13)
+
+
+def test_strong_scaling_rows_partition_the_base_grid():
+    """bench.py --scaling strong: rank r of N takes rows r, r + N, ... of the N = 1 grid itself."""
+    base = ol.oracle_pointsource(bench.make_spec(capi, D))
+    live = base["steps"] != -1
+    glob = np.stack([base["alpha"][live], base["beta"][live]], 1)
+    for world in (2, 3):
+        parts = []
+        for r in range(world):
+            rays = ol.oracle_pointsource(bench.make_spec(capi, D, r, world, strong=True))
+            m = rays["steps"] != -1
+            parts.append(np.stack([rays["alpha"][m], rays["beta"][m]], 1))
+        union = np.concatenate(parts)
+        assert len(union) == len(glob)
+        key = lambda a: np.lexsort((a[:, 1], a[:, 0]))
+        np.testing.assert_allclose(union[key(union)], glob[key(glob)], rtol=0, atol=1e-12)
+        sizes = [len(x) for x in parts]
+        assert max(sizes) - min(sizes) <= len(glob) // len(np.unique(glob[:, 0])) + 1      # balanced to within one row
