@@ -316,6 +316,14 @@ int kr_reduce_return_dev_f64(const kr_return_bins* b, const void* d_rays, int64_
  * 4 sin(a)  5 cos(a) (compact polar-angle sincos)  6 a*rcp(b)  7 sqrt(a) (fast-math path)  8 sin  9 cos  10 pow(a,b) (device libm) */
 int kr_debug_arith_f64(int op, const double* a, const double* b, double* out, int64_t n);
 
+/* ---- a long-lived host ray array (what Raytracer<T> holds as `rays`) ----------------------------- */
+/* kr_host_attach keeps a device buffer for the array until kr_host_detach.  Host-pointer entry points called on an attached array
+ * (or on a sub-range of it) allocate nothing and copy back only what their pass modifies: `emit` (redshift_start), `phi` (range_phi), `redshift` (redshift*), the four momenta (calculate_momentum),
+ * the whole record (trace, the source constructors).  Semantics are unchanged: the host array is the input of every call and is
+ * complete when the call returns.  ray_bytes = sizeof(kr_ray_f64) or sizeof(kr_ray_f32).  Detach before freeing the array. */
+int kr_host_attach(void* rays, int64_t n, int32_t ray_bytes);
+int kr_host_detach(void* rays);
+
 /* ---- device memory helpers for callers without a HIP runtime of their own --------------------- */
 int kr_malloc(void** d_ptr, int64_t bytes);
 int kr_free(void* d_ptr);

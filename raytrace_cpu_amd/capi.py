@@ -148,6 +148,8 @@ PROTOTYPES = {
     "kr_reduce_return_f64": (_int, [P(ReturnBins), _vp, _i64, P(_dbl * 4)]),
     "kr_reduce_return_dev_f64": (_int, [P(ReturnBins), _vp, _i64, _vp, _vp]),
     "kr_debug_arith_f64": (_int, [_int, _vp, _vp, _vp, _i64]),
+    "kr_host_attach": (_int, [_vp, _i64, _i32]),
+    "kr_host_detach": (_int, [_vp]),
     "kr_malloc": (_int, [P(_vp), _i64]),
     "kr_free": (_int, [_vp]),
     "kr_host_alloc": (_int, [P(_vp), _i64]),

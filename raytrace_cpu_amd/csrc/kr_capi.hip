@@ -8,8 +8,13 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kr_common.hpp"
@@ -72,33 +77,113 @@ namespace {
 using clk = std::chrono::steady_clock;
 double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
 
-// run `body(d_rays)` on a device copy of a host ray array and copy the array back
+// ---- attached host arrays ----------------------------------------------------------------------------------------------
+// A caller that keeps ONE host ray array through several passes (the class API: Raytracer<T>::rays lives as long as the object)
+// attaches it once: a device buffer of the same size is kept for it, and every host-pointer entry point called on it (a) allocates
+// nothing, (b) copies back only the bytes its pass modifies -- one 8-byte field per record for redshift_start / range_phi /
+// redshift -- through a compact buffer: field-gather kernel, 8 n bytes over PCIe, scatter into rays[] by host threads.
+// (Page-locking the array in place with hipHostRegister was measured and dropped: transfers do reach 57 GB/s, but registering
+// 1.44 GB costs ~60 ms, the first transfer out of it 140 ms, unregistering ~100 ms -- more than four passes save;
+// the runtime's own path for pageable memory already runs at 30-55 GB/s after the first touch: profiles/r02_app_wall.txt.)
+// The host array is still the input of every call (it is uploaded each time: an application may have written to it) and is
+// complete when the call returns, which is the reference's contract.
+struct Attached {
+    void* host = nullptr;
+    int64_t n = 0;
+    size_t ray_bytes = 0;
+    void* dev = nullptr;          // n * ray_bytes
+    void* d_field = nullptr;      // n * 32: the widest partial write-back (four momenta)
+    void* h_field = nullptr;      // host side of it
+};
+std::mutex g_att_mu;
+std::map<const void*, Attached> g_attached;
+
+__global__ void __launch_bounds__(256) gather_field_kernel(const char* __restrict__ rays, long long n, int ray_bytes, int off, int words, double* __restrict__ out)
+{
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long) gridDim.x * 256) {
+        const double* src = reinterpret_cast<const double*>(rays + i * ray_bytes + off);
+        for (int w = 0; w < words; w++) out[i * words + w] = src[w];
+    }
+}
+
+void scatter_field_host(char* rays, int64_t n, size_t ray_bytes, int off, int words, const double* field)
+{
+    const int nthreads = (int) std::max<int64_t>(1, std::min<int64_t>(8, n / 65536));
+    auto work = [&](int t) {
+        const int64_t lo = n * t / nthreads, hi = n * (t + 1) / nthreads;
+        for (int64_t i = lo; i < hi; i++) std::memcpy(rays + i * ray_bytes + off, field + i * words, (size_t) words * 8);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+}
+
+// what a pass writes into the records it was given
+struct WriteBack {
+    int off = 0;         // byte offset of the modified field(s) inside a record
+    int words = 0;       // 8-byte words; 0 = the whole record
+};
+constexpr WriteBack kWholeRecord = {0, 0};
+
+// run `body(d_rays)` on a device copy of a host ray array and copy the result back
 template <typename Body>
-int with_staged_rays(void* rays, int64_t n, size_t ray_bytes, bool copy_in, bool copy_out, kr_stats* stats, Body body)
+int with_staged_rays(void* rays, int64_t n, size_t ray_bytes, bool copy_in, bool copy_out, kr_stats* stats, Body body, WriteBack wb = kWholeRecord)
 {
     if (n < 0 || (n > 0 && !rays)) { set_error("null rays pointer or negative n"); return KR_EINVAL; }
     int rc = require_device();
     if (rc != KR_OK) return rc;
     if (n == 0) return body(nullptr);
     static const bool timing = getenv("KR_TIMING") != nullptr;      // per-call breakdown on stderr (scripts/app_wall.sh)
+    Attached att;
+    {
+        std::lock_guard<std::mutex> lk(g_att_mu);
+        // an attached array, or a sub-range of one (the single-ray propagate() forms pass &rays[i])
+        auto it = g_attached.upper_bound(rays);
+        if (it != g_attached.begin()) {
+            --it;
+            const char* base = (const char*) it->second.host;
+            const char* p = (const char*) rays;
+            if (it->second.ray_bytes == ray_bytes && p >= base && p + (size_t) n * ray_bytes <= base + (size_t) it->second.n * ray_bytes &&
+                (size_t) (p - base) % ray_bytes == 0)
+                att = it->second;
+        }
+    }
     auto t0 = clk::now();
     DeviceBuffer buf;
-    rc = buf.alloc((size_t) n * ray_bytes);
-    if (rc != KR_OK) return rc;
+    char* d = nullptr;
+    if (att.dev) {
+        d = (char*) att.dev + ((const char*) rays - (const char*) att.host);
+    } else {
+        rc = buf.alloc((size_t) n * ray_bytes);
+        if (rc != KR_OK) return rc;
+        d = (char*) buf.p;
+    }
     const double t_alloc = ms_since(t0);
     t0 = clk::now();
-    if (copy_in) KR_HIP(hipMemcpy(buf.p, rays, (size_t) n * ray_bytes, hipMemcpyHostToDevice));
+    if (copy_in) KR_HIP(hipMemcpy(d, rays, (size_t) n * ray_bytes, hipMemcpyHostToDevice));
     const double h2d = ms_since(t0);
     t0 = clk::now();
-    rc = body(buf.p);
+    rc = body((void*) d);
     if (rc != KR_OK) return rc;
     KR_HIP(hipDeviceSynchronize());
     const double t_body = ms_since(t0);
     t0 = clk::now();
-    if (copy_out) KR_HIP(hipMemcpy(rays, buf.p, (size_t) n * ray_bytes, hipMemcpyDeviceToHost));
+    if (copy_out) {
+        if (att.dev && wb.words > 0 && wb.words <= 4 && n >= 4096) {
+            hipLaunchKernelGGL(gather_field_kernel, dim3((unsigned) std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, nullptr, (const char*) d, (long long) n,
+                               (int) ray_bytes, wb.off, wb.words, (double*) att.d_field);
+            KR_HIP(hipGetLastError());
+            KR_HIP(hipMemcpy(att.h_field, att.d_field, (size_t) n * wb.words * 8, hipMemcpyDeviceToHost));
+            scatter_field_host((char*) rays, n, ray_bytes, wb.off, wb.words, (const double*) att.h_field);
+        } else {
+            KR_HIP(hipMemcpy(rays, d, (size_t) n * ray_bytes, hipMemcpyDeviceToHost));
+        }
+    }
     const double d2h = ms_since(t0);
     if (stats) { stats->h2d_ms = h2d; stats->d2h_ms = d2h; }
-    if (timing) std::fprintf(stderr, "kr_timing: staged call n=%lld alloc %.1f ms h2d %.1f ms kernels %.1f ms d2h %.1f ms\n", (long long) n, t_alloc, h2d, t_body, d2h);
+    if (timing) std::fprintf(stderr, "kr_timing: staged call n=%lld%s alloc %.1f ms h2d %.1f ms kernels %.1f ms d2h %.1f ms%s\n", (long long) n, att.dev ? " (attached)" : "",
+                             t_alloc, h2d, t_body, d2h, (att.dev && wb.words > 0) ? " (one field)" : "");
     return KR_OK;
 }
 
@@ -258,7 +343,7 @@ int kr_redshift_start_dev_f64(double spin, double V, int reverse, int projradius
 int kr_redshift_start_f64(double spin, double V, int reverse, int projradius, kr_ray_f64* rays, int64_t n)
 {
     return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
-                            [&](void* d) { return redshift_start_dev(spin, V, reverse, projradius, d, n, nullptr); });
+                            [&](void* d) { return redshift_start_dev(spin, V, reverse, projradius, d, n, nullptr); }, WriteBack{offsetof(kr_ray_f64, emit), 1});
 }
 
 int kr_redshift_dev_f64(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, void* st)
@@ -269,7 +354,7 @@ int kr_redshift_dev_f64(double spin, double V, int reverse, int projradius, int 
 int kr_redshift_f64(double spin, double V, int reverse, int projradius, int motion, kr_ray_f64* rays, int64_t n)
 {
     return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
-                            [&](void* d) { return redshift_dev(spin, V, reverse, projradius, motion, d, n, nullptr); });
+                            [&](void* d) { return redshift_dev(spin, V, reverse, projradius, motion, d, n, nullptr); }, WriteBack{offsetof(kr_ray_f64, redshift), 1});
 }
 
 int kr_redshift_dest_dev_f64(double spin, int reverse, void* d, int64_t n, void* st)
@@ -280,7 +365,7 @@ int kr_redshift_dest_dev_f64(double spin, int reverse, void* d, int64_t n, void*
 int kr_redshift_dest_f64(double spin, int reverse, kr_ray_f64* rays, int64_t n)
 {
     return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
-                            [&](void* d) { return redshift_dest_dev(spin, reverse, d, n, nullptr); });
+                            [&](void* d) { return redshift_dest_dev(spin, reverse, d, n, nullptr); }, WriteBack{offsetof(kr_ray_f64, redshift), 1});
 }
 
 int kr_range_phi_dev_f64(double lo, double hi, void* d, int64_t n, void* st)
@@ -291,7 +376,7 @@ int kr_range_phi_dev_f64(double lo, double hi, void* d, int64_t n, void* st)
 int kr_range_phi_f64(double lo, double hi, kr_ray_f64* rays, int64_t n)
 {
     return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
-                            [&](void* d) { return range_phi_dev(lo, hi, d, n, nullptr); });
+                            [&](void* d) { return range_phi_dev(lo, hi, d, n, nullptr); }, WriteBack{offsetof(kr_ray_f64, phi), 1});
 }
 
 int kr_calculate_momentum_dev_f64(double spin, void* d, int64_t n, void* st)
@@ -302,7 +387,7 @@ int kr_calculate_momentum_dev_f64(double spin, void* d, int64_t n, void* st)
 int kr_calculate_momentum_f64(double spin, kr_ray_f64* rays, int64_t n)
 {
     return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
-                            [&](void* d) { return calculate_momentum_dev(spin, d, n, nullptr); });
+                            [&](void* d) { return calculate_momentum_dev(spin, d, n, nullptr); }, WriteBack{offsetof(kr_ray_f64, pt), 4});
 }
 
 // ---- sources -----------------------------------------------------------------------------------------------
@@ -494,6 +579,45 @@ int kr_debug_arith_f64(int op, const double* a, const double* b, double* out, in
     rc = arith_probe_dev(op, (const double*) da.p, (const double*) db.p, (double*) dout.p, n);
     if (rc != KR_OK) return rc;
     KR_HIP(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+    return KR_OK;
+}
+
+// ---- attached host arrays (see with_staged_rays) --------------------------------------------------------------------------
+int kr_host_attach(void* rays, int64_t n, int32_t ray_bytes)
+{
+    if (!rays || n <= 0 || (ray_bytes != (int32_t) sizeof(kr_ray_f64) && ray_bytes != (int32_t) sizeof(kr_ray_f32))) { set_error("kr_host_attach: bad argument"); return KR_EINVAL; }
+    int rc = require_device();
+    if (rc != KR_OK) return rc;
+    Attached a;
+    a.host = rays; a.n = n; a.ray_bytes = (size_t) ray_bytes;
+    {
+        std::lock_guard<std::mutex> lk(g_att_mu);
+        if (g_attached.count(rays)) { set_error("kr_host_attach: array is already attached"); return KR_EINVAL; }
+    }
+    auto undo = [&]() { if (a.dev) (void) hipFree(a.dev); if (a.d_field) (void) hipFree(a.d_field); std::free(a.h_field); };
+    hipError_t e = hipMalloc(&a.dev, (size_t) n * ray_bytes);
+    if (e == hipSuccess) e = hipMalloc(&a.d_field, (size_t) n * 32);
+    if (e == hipSuccess && !(a.h_field = std::malloc((size_t) n * 32))) e = hipErrorOutOfMemory;
+    if (e != hipSuccess) { undo(); return hip_fail(e, "kr_host_attach allocation", __FILE__, __LINE__); }
+    std::lock_guard<std::mutex> lk(g_att_mu);
+    g_attached[rays] = a;
+    return KR_OK;
+}
+
+int kr_host_detach(void* rays)
+{
+    Attached a;
+    {
+        std::lock_guard<std::mutex> lk(g_att_mu);
+        auto it = g_attached.find(rays);
+        if (it == g_attached.end()) return KR_OK;
+        a = it->second;
+        g_attached.erase(it);
+    }
+    (void) hipFree(a.dev);
+    (void) hipFree(a.d_field);
+    std::free(a.h_field);
+    (void) hipGetLastError();
     return KR_OK;
 }
 

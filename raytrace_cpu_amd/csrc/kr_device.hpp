@@ -329,26 +329,36 @@ KR_DEV void momentum_fast_sc(double& pt, double& pr, double& ptheta, double& pph
 {
 #pragma clang fp contract(fast)
     const double s2 = s * s;
-    const double ac = a * c;
+    const double c2 = c * c;
     const double r2 = r * r;
-    const double rhosq = r2 + ac * ac;
-    const double delta = r2 - 2 * r + a * a;
+    const double a2 = a * a;
+    const double rhosq = __builtin_fma(a2, c2, r2);
+    const double delta = r2 - 2 * r + a2;
     const double rd = rhosq * delta;
     const double inv = fast_rcp(rd * s2);          // 1 / (rho^2 Delta sin^2)
     const double inv_rd = inv * s2;                // 1 / (rho^2 Delta)
     const double inv_rho = inv_rd * delta;         // 1 / rho^2
     const double inv_s2 = inv * rd;                // 1 / sin^2
-    const double ar2 = 2 * a * r;
 
-    pt = ((rhosq * (r2 + a * a) + ar2 * a * s2) * k - ar2 * h) * inv_rd;
-    pphi = (ar2 * s2 * k + (rhosq - 2 * r) * h) * inv;
+    // The same four derivatives through the separated potentials (Carter): with P = (r^2 + a^2) k - a h,
+    //   rho^2 tdot   = -a (a k sin^2 - h) + (r^2 + a^2) P / Delta        rho^4 thetadot^2 = Q + cos^2 (k^2 a^2 - h^2 / sin^2)
+    //   rho^2 phidot = -(a k - h / sin^2) + a P / Delta                  rho^4 rdot^2     = P^2 - Delta (Q + (h - a k)^2)
+    // -- algebraically what kerr.h:300-335 evaluates (its rdot^2 = (k tdot - h phidot - rho^2 thetadot^2) Delta / rho^2 is the null
+    // condition solved for rdot), in 60 operations instead of 64, and the radial equation no longer waits for tdot and phidot.
+    const double ak = a * k, ah = a * h;                 // (loop-invariant per ray, like h^2, k^2 a^2 and the Carter term below)
+    const double P = __builtin_fma(r2 + a2, k, -ah);
+    pt = __builtin_fma(-(__builtin_fma(a * ak, s2, -ah)), inv_rho, ((r2 + a2) * P) * inv_rd);
+    pphi = __builtin_fma(__builtin_fma(h, inv_s2, -ak), inv_rho, (a * P) * inv_rd);
 
-    const double kac = k * ac;
-    const double hcs = h * c * s * inv_s2;         // h cos / sin
-    const double thsq = (Q + (kac + hcs) * (kac - hcs)) * (inv_rho * inv_rho);
+    const double num = __builtin_fma(c2, __builtin_fma(-(h * h), inv_s2, ak * ak), Q);
+    const double inv_rho2 = inv_rho * inv_rho;
+    const double thsq = num * inv_rho2;
     ptheta = fast_sqrt(__builtin_fabs(thsq)) * thetadot_sign;
 
-    const double rsq = (k * pt - h * pphi - rhosq * ptheta * ptheta) * delta * inv_rho;
+    // (kerr.h:327-333 builds rdot^2 from |thetadot^2|: beyond a polar turning point, where a Runge-Kutta stage may land, that differs
+    // from the analytic radial potential by 2 |thetadot^2| Delta -- an O(step^3) kink the reference's solution contains, so it is kept)
+    const double hmak = h - ak;
+    const double rsq = __builtin_fma(-delta, __builtin_fabs(thsq) - thsq, __builtin_fma(-delta, __builtin_fma(hmak, hmak, Q), P * P) * inv_rho2);
     pr = fast_sqrt(__builtin_fabs(rsq)) * rdot_sign;
     if (aux) { aux->rhosq = rhosq; aux->sin2theta = s2; aux->inv_rhosq = inv_rho; }
     if (thetadotsq_o) *thetadotsq_o = thsq;
@@ -406,23 +416,25 @@ KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
     double sn, c;
     kr_sincos_fast_f64(theta, sn, c);   // (carrying sin/cos from step to step by angle addition was measured 6 % SLOWER)
     const double s2 = sn * sn;
-    const double ac = a * c;
+    const double c2 = c * c;
     const double r2 = r * r;
-    const double rhosq = r2 + ac * ac;
-    const double delta = r2 - 2 * r + a * a;
+    const double a2 = a * a;
+    const double rhosq = __builtin_fma(a2, c2, r2);
+    const double delta = r2 - 2 * r + a2;
     const double rd = rhosq * delta;
     const double inv = fast_rcp(rd * s2);
     const double inv_rd = inv * s2;
     const double inv_rho = inv_rd * delta;
     const double inv_s2 = inv * rd;
-    const double ar2 = 2 * a * r;
 
-    s.pt = ((rhosq * (r2 + a * a) + ar2 * a * s2) * k - ar2 * h) * inv_rd;
-    s.pphi = (ar2 * s2 * k + (rhosq - 2 * r) * h) * inv;
+    const double ak = a * k, ah = a * h;                 // see momentum_fast_sc
+    const double P = __builtin_fma(r2 + a2, k, -ah);
+    s.pt = __builtin_fma(-(__builtin_fma(a * ak, s2, -ah)), inv_rho, ((r2 + a2) * P) * inv_rd);
+    s.pphi = __builtin_fma(__builtin_fma(h, inv_s2, -ak), inv_rho, (a * P) * inv_rd);
 
-    const double kac = k * ac;
-    const double hcs = h * c * sn * inv_s2;
-    const double thetadotsq = (s.Q + (kac + hcs) * (kac - hcs)) * (inv_rho * inv_rho);
+    const double num = __builtin_fma(c2, __builtin_fma(-(h * h), inv_s2, ak * ak), s.Q);
+    const double inv_rho2 = inv_rho * inv_rho;
+    const double thetadotsq = num * inv_rho2;
     if (thetadotsq < 0 && s.theta_was_positive) {
         s.thetadot_sign = -s.thetadot_sign;
         s.theta_was_positive = false;
@@ -431,7 +443,8 @@ KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
     if (thetadotsq >= 0) s.theta_was_positive = true;
     s.ptheta = fast_sqrt(__builtin_fabs(thetadotsq)) * s.thetadot_sign;
 
-    const double rdotsq = (k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta) * delta * inv_rho;
+    const double hmak = h - ak;
+    const double rdotsq = __builtin_fma(-delta, __builtin_fabs(thetadotsq) - thetadotsq, __builtin_fma(-delta, __builtin_fma(hmak, hmak, s.Q), P * P) * inv_rho2);
     if (rdotsq <= 0 && s.r_was_positive) {
         s.rdot_sign = -s.rdot_sign;
         s.r_was_positive = false;
@@ -516,6 +529,8 @@ KR_DEV T dest_step_limit(const TraceConsts<T>& c, T r, T theta, T ptheta)
 template <typename T>
 KR_DEV void reflect_poles(T& theta, T& phi, int32_t& thetadot_sign)
 {
+    // a pole crossing is rare: one wave-uniform test, and the per-lane selects only in a wave that has one
+    if (__builtin_amdgcn_ballot_w64(theta < T(0) || theta > T(kPi)) == 0) return;
     if (theta < T(0)) { theta = -theta; thetadot_sign = -thetadot_sign; phi += T(kPi); }
     if (theta > T(kPi)) { theta = T(2) * T(kPi) - theta; thetadot_sign = -thetadot_sign; phi += T(kPi); }
 }

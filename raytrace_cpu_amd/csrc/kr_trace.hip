@@ -153,6 +153,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
 #if KR_LONG_RAY_PRIO
     int has_prio = 0;
+    unsigned prio_tick = 0;
 #endif
 
     for (;;) {
@@ -200,7 +201,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
         if (!any_have) break;   // nothing held and (exhausted or nothing needed): only reachable when exhausted
 
 #if KR_LONG_RAY_PRIO
-        if constexpr (!HOG)                    // (a wave that owns its SIMD has nobody to take priority over)
+        if (!HOG && (++prio_tick & 15) == 0)   // (a wave that owns its SIMD has nobody to take priority over; the thresholds are thousands of steps)
         // The launch cannot end before its longest ray does, and a ray advances one step per iteration of ITS wave:
         // a wave that carries a long ray (orbiting / polar-axis rays: 2e4..1e7 steps against a median of ~450) is
         // given issue priority over its SIMD neighbours so that the critical path runs at single-wave speed

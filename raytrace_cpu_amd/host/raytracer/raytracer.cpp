@@ -9,9 +9,16 @@
 
 #include "raytracer.h"
 
+#include <sys/mman.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <type_traits>
 #include <typeinfo>
 
 #include "../../../include/kr_trace.h"
@@ -21,6 +28,15 @@ static_assert(sizeof(Ray<double>) == sizeof(kr_ray_f64), "Ray<double> must be la
 static_assert(sizeof(Ray<float>) == sizeof(kr_ray_f32), "Ray<float> must be layout-identical to kr_ray_f32");
 
 namespace {
+
+// KR_TIMING=1: wall-clock marks on stderr, relative to the first mark, around what the mirror does (scripts/app_wall.sh)
+void mark(const char* what)
+{
+    static const bool on = std::getenv("KR_TIMING") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "kr_timing: t = %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+}
 
 [[noreturn]] void fail(const char* what, int rc)
 {
@@ -65,18 +81,42 @@ Raytracer<T>::Raytracer(int num_rays, T spin_par, T init_precision, T init_max_p
       nRays(num_rays),
       spin(spin_par)
 {
+    mark("Raytracer ctor: begin");
     horizon = kerr_horizon<T>(spin);
-    rays = new Ray<T>[nRays]();          // value-initialised
+    // Every record zeroed, steps = -1 (the reference leaves most fields indeterminate).  At 1e7 rays the array is 1.44 GB: `new
+    // Ray<T>[n]()` + a second serial pass cost ~0.35 s of page faults and stores on one core -- more than the whole GPU trace --
+    // so the memory is taken raw and first touched by all host threads at once (Ray<T> is trivially constructible).  (Any array the
+    // reference's delete[] would have released is released here by the matching free(): applications never free `rays` themselves.)
+    static_assert(std::is_trivially_copyable<Ray<T>>::value && std::is_trivially_destructible<Ray<T>>::value, "Ray<T> must be a plain record");
+    const size_t bytes = sizeof(Ray<T>) * static_cast<size_t>(nRays > 0 ? nRays : 0);
+    // 2-MB aligned and advised for transparent huge pages where the kernel allows: 512 x fewer page faults on the first touch
+    const size_t huge = size_t(2) << 20;
+    void* mem = nullptr;
+    if (posix_memalign(&mem, bytes >= huge ? huge : 64, bytes ? ((bytes + huge - 1) / huge) * huge : 64) != 0) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+    if (bytes >= huge) (void) madvise(mem, ((bytes + huge - 1) / huge) * huge, MADV_HUGEPAGE);
+#endif
+    rays = static_cast<Ray<T>*>(mem);
+    // the HIP runtime takes ~0.15 s to come up in a fresh process: let it do so on a thread of its own while this one touches rays[]
+    std::thread warm_up([] { (void) kr_device_count(); });
+#pragma omp parallel for schedule(static)
     for (int ray = 0; ray < nRays; ray++) {
+        std::memset(static_cast<void*>(&rays[ray]), 0, sizeof(Ray<T>));
         rays[ray].steps = -1;
-        rays[ray].status = 0;
     }
+    warm_up.join();
+    mark("Raytracer ctor: rays[] allocated and first touched");
+    if (nRays > 0) (void) kr_host_attach(rays, nRays, (int32_t) sizeof(Ray<T>));
+    mark("Raytracer ctor: attached (device buffer)");
 }
 
 template <typename T>
 Raytracer<T>::~Raytracer()
 {
-    delete[] rays;
+    mark("Raytracer dtor: begin");
+    (void) kr_host_detach(rays);
+    std::free(static_cast<void*>(rays));
+    mark("Raytracer dtor: end");
 }
 
 // Arithmetic of the double-precision trace (include/kr_trace.h), chosen by the environment so that
@@ -117,7 +157,9 @@ void Raytracer<T>::fill_params(void* out, Integrator method, T r_max, int stepli
 template <typename T>
 void Raytracer<T>::trace(const void* params, Ray<T>* first, long n)
 {
+    if (n > 1) mark("run_raytrace: begin");
     check(trace_call(static_cast<const kr_params*>(params), first, n), "kr_trace");
+    if (n > 1) mark("run_raytrace: end");
 }
 
 template <typename T>
@@ -293,7 +335,9 @@ template <typename T>
 void Raytracer<T>::redshift_start(T V, bool reverse, bool projradius)
 {
     if (OnDevice<T>::value) {
+        mark("redshift_start: begin");
         check(kr_redshift_start_f64(spin, V, reverse, projradius, as_kr(rays), nRays), "kr_redshift_start");
+        mark("redshift_start: end");
         return;
     }
     // host loop; V carries over from ray to ray once replaced, exactly like the reference's by-value parameter
@@ -318,7 +362,9 @@ template <typename T>
 void Raytracer<T>::redshift(T V, bool reverse, bool projradius, int motion)
 {
     if (OnDevice<T>::value) {
+        mark("redshift: begin");
         check(kr_redshift_f64(spin, V, reverse, projradius, motion, as_kr(rays), nRays), "kr_redshift");
+        mark("redshift: end");
         return;
     }
     for (int ray = 0; ray < nRays; ray++) {
@@ -351,7 +397,9 @@ template <typename T>
 void Raytracer<T>::range_phi(T min, T max)
 {
     if (OnDevice<T>::value) {
+        mark("range_phi: begin");
         check(kr_range_phi_f64(min, max, as_kr(rays), nRays), "kr_range_phi");
+        mark("range_phi: end");
         return;
     }
     for (int ray = 0; ray < nRays; ray++) {

@@ -8,7 +8,7 @@ NATIVE=$ROOT/raytrace_cpu_amd/apps/_build
 DROPIN=$ROOT/dropin/_build
 export LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6
 W=$(mktemp -d)
-timed() { local t0=$(date +%s%N); "$@" 2>&1 | grep -E "timing|rror" ; local t1=$(date +%s%N); echo "wall $(( (t1 - t0) / 1000000 )) ms"; }
+timed() { local t0=$(date +%s%N); "$@" 2>&1 | grep -E "timing|rror" | cut -c1-200 ; local t1=$(date +%s%N); echo "wall $(( (t1 - t0) / 1000000 )) ms"; }
 {
 for rep in 1 2; do
   echo "== kr_emissivity (device-resident), emissivity_c2.par, run $rep"
