@@ -234,6 +234,11 @@ int kr_trace_dev_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, 
  * outstanding per device).  kr_trace_dev_*(.., stats) == async + wait;  (.., NULL) == async + release. */
 int kr_trace_async_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, void** ticket);
 int kr_trace_async_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, void** ticket);
+/* `count` traces at once (one per tolerance of a sweep, per source radius, ...), each on its own stream and ray buffer: the strict
+ * side launches of ALL of them -- the few waves that carry each launch's longest rays -- are enqueued before any main launch, so they
+ * are placed while the chip is empty and the tails run side by side; strict traces are split whatever their size (>= 4096 rays).
+ * Same results as `count` kr_trace_async_f64 calls, bit for bit.  streams may be NULL (all on the default stream). */
+int kr_trace_batch_async_f64(int32_t count, const kr_params* const* p, void* const* d_rays, const int64_t* n, void* const* streams, void** tickets);
 int kr_trace_wait(void* ticket, kr_stats* stats);
 int kr_trace_release(void* ticket);
 
@@ -313,7 +318,8 @@ int kr_reduce_return_dev_f64(const kr_return_bins* b, const void* d_rays, int64_
 /* ---- diagnostics ------------------------------------------------------------------------------- */
 /* out[i] = op(a[i], b[i]) evaluated ON THE DEVICE with the exact primitive the trace kernel uses (host pointers):
  * 0 a/b (compiler IEEE)  1 a/b (lean IEEE chain of the strict path)  2 sqrt(a) (compiler)  3 sqrt(a) (lean)
- * 4 sin(a)  5 cos(a) (compact polar-angle sincos)  6 a*rcp(b)  7 sqrt(a) (fast-math path)  8 sin  9 cos  10 pow(a,b) (device libm) */
+ * 4 sin(a)  5 cos(a) (compact polar-angle sincos)  6 a*rcp(b)  7 sqrt(a) (fast-math path)  8 sin  9 cos  10 pow(a,b) (device libm)
+ * 11-18 further primitives of the two arithmetic paths (kr_post.hip::arith_probe_kernel)  19 a after 20 000 additions of b (kr_replay.hpp) */
 int kr_debug_arith_f64(int op, const double* a, const double* b, double* out, int64_t n);
 
 /* ---- a long-lived host ray array (what Raytracer<T> holds as `rays`) ----------------------------- */

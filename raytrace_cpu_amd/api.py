@@ -70,6 +70,18 @@ def trace_async(params, d_ptr, n, stream=None, f32=False):
     return ticket
 
 
+def trace_batch_async(params_list, d_ptrs, ns, streams=None):
+    """kr_trace_batch_async_f64: all strict side launches first, then all main launches.  Returns one ticket per trace."""
+    count = len(params_list)
+    pp = (C.POINTER(Params) * count)(*[C.pointer(p) for p in params_list])
+    dd = (C.c_void_p * count)(*[C.c_void_p(d) for d in d_ptrs])
+    nn = (C.c_int64 * count)(*ns)
+    ss = (C.c_void_p * count)(*[C.c_void_p(s or 0) for s in (streams or [0] * count)])
+    tt = (C.c_void_p * count)()
+    capi.check(lib(), lib().kr_trace_batch_async_f64(count, pp, dd, nn, ss, tt), "kr_trace_batch_async")
+    return [C.c_void_p(t) for t in tt]
+
+
 def trace_wait(ticket, want_stats=True):
     st = Stats() if want_stats else None
     capi.check(lib(), lib().kr_trace_wait(ticket, C.byref(st) if st else None), "kr_trace_wait")

@@ -118,6 +118,7 @@ PROTOTYPES = {
     "kr_trace_dev_f32": (_int, [P(Params), _vp, _i64, _vp, P(Stats)]),
     "kr_trace_async_f64": (_int, [P(Params), _vp, _i64, _vp, P(_vp)]),
     "kr_trace_async_f32": (_int, [P(Params), _vp, _i64, _vp, P(_vp)]),
+    "kr_trace_batch_async_f64": (_int, [_i32, P(P(Params)), P(_vp), P(_i64), P(_vp), P(_vp)]),
     "kr_trace_wait": (_int, [_vp, P(Stats)]),
     "kr_trace_release": (_int, [_vp]),
     "kr_redshift_start_f64": (_int, [_dbl, _dbl, _int, _int, _vp, _i64]),

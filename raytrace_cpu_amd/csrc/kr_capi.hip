@@ -310,6 +310,11 @@ int kr_trace_async_f32(const kr_params* p, void* d_rays, int64_t n, void* stream
     return trace_async(p, d_rays, n, (hipStream_t) stream, true, ticket);
 }
 
+int kr_trace_batch_async_f64(int32_t count, const kr_params* const* p, void* const* d_rays, const int64_t* n, void* const* streams, void** tickets)
+{
+    return trace_batch_async(count, p, d_rays, n, streams, tickets);
+}
+
 int kr_trace_wait(void* ticket, kr_stats* stats) { return trace_wait(ticket, stats); }
 
 int kr_trace_release(void* ticket)

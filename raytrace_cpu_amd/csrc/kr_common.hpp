@@ -31,6 +31,7 @@ struct DeviceBuffer {
 // device-pointer implementations (defined in kr_trace.hip / kr_post.hip); stream may be null
 int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, kr_stats* stats, bool f32);
 int trace_async(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, bool f32, void** ticket);
+int trace_batch_async(int count, const kr_params* const* p, void* const* d_rays, const int64_t* n, void* const* streams, void** tickets);
 int trace_wait(void* ticket, kr_stats* stats);
 void trace_release(void* ticket);
 

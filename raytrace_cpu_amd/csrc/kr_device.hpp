@@ -16,6 +16,7 @@
 
 #include "../../include/kr_trace.h"
 #include "kr_sincos.hpp"
+#include "kr_replay.hpp"
 
 namespace kr {
 
@@ -949,9 +950,16 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
         s.steps < c.steplim) {
         const T dt = h_try * sum_t, dphi = h_try * sum_phi;
         const int32_t remaining = c.steplim - s.steps;
-        for (int32_t i = 0; i < remaining; ++i) {
-            s.t = s.t + dt;
-            s.phi = s.phi + dphi;
+        if constexpr (sizeof(T) == 8) {
+            // the `remaining` additions to t and to phi, each rounded as the loop would round it, in closed form per binade
+            // (kr_replay.hpp; bit-identical to the loop, which used to hold the other 63 lanes of the wave for ~0.7 ms per captured ray)
+            s.t = kr_replay_additions(s.t, dt, (long long) remaining);
+            s.phi = kr_replay_additions(s.phi, dphi, (long long) remaining);
+        } else {
+            for (int32_t i = 0; i < remaining; ++i) {
+                s.t = s.t + dt;
+                s.phi = s.phi + dphi;
+            }
         }
         s.steps = c.steplim;
         attempts += (uint32_t) remaining;

@@ -575,6 +575,7 @@ __global__ void __launch_bounds__(kBlock) arith_probe_kernel(int op, const doubl
             case 14: { double v = __builtin_amdgcn_rsq(x); double g = x * v, h = 0.5 * v; const double e = __builtin_fma(-h, g, 0.5);
                        r = __builtin_fma(g, e, g); } break;                                                                  // + one coupled step
             case 18: r = fifth_root_for_controller(x); break;                        // x^(1/5) of the RK45 step controller
+            case 19: r = kr_replay_additions(x, y, 20000); break;                    // 20 000 additions of y to x in closed form (kr_replay.hpp)
             case 17: r = div_by_uniform(x, y, 1.0 / y, true); break;                 // quotient by a launch-uniform divisor (IEEE reciprocal)
             case 15: kr_sincos_fast_f64(x, s, c); r = s; break;
             case 16: kr_sincos_fast_f64(x, s, c); r = c; break;

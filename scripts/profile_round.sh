@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes for the bench workload.
-# usage: scripts/profile_r01.sh <tag> [bench args...]
+# usage: scripts/profile_round.sh <tag> [bench args...]
 set -o pipefail
-TAG=${1:-r01}; shift
+TAG=${1:-r02}; shift
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG

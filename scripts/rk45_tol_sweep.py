@@ -76,11 +76,8 @@ for h in (5.0, 10.0):
         p = capi.default_params(gc.SPIN); p.integrator, p.rk45_tol, p.flags = capi.RK45, tol, ARITH
         points.append(dict(h=h, tol=tol, spec=spec, n=n, bins=bins, d_rays=d_rays, d_hist=d_hist, stream=stream, p=p))
 
-def enqueue(pt):
-    capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(pt["spec"]), 0, 1, 0.0, 0, 0, pt["d_rays"], pt["n"], pt["stream"]), "init")
-    t = api.trace_async(pt["p"], pt["d_rays"].value, pt["n"], stream=pt["stream"].value)
+def post(pt):
     capi.check(lib, lib.kr_post_emissivity_dev_f64(gc.SPIN, -1.0, 0, 0, 0, -math.pi, math.pi, C.byref(pt["bins"]), pt["d_rays"], pt["n"], pt["d_hist"], pt["stream"]), "post")
-    return t
 
 walls = []
 for rnd in range(3):
@@ -88,7 +85,12 @@ for rnd in range(3):
         capi.check(lib, lib.kr_memset(pt["d_hist"], 0, (5 * pt["bins"].nr + 1) * 8), "memset")
     capi.check(lib, lib.kr_synchronize(None), "sync")
     t0 = time.perf_counter()
-    tickets = [enqueue(pt) for pt in points]
+    for pt in points:
+        capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(pt["spec"]), 0, 1, 0.0, 0, 0, pt["d_rays"], pt["n"], pt["stream"]), "init")
+    # one batch: the strict side launches of all 18 points go to the device before any main launch (kr_trace_batch_async_f64)
+    tickets = api.trace_batch_async([pt["p"] for pt in points], [pt["d_rays"].value for pt in points], [pt["n"] for pt in points], [pt["stream"].value for pt in points])
+    for pt in points:
+        post(pt)
     stats = [api.trace_wait(t) for t in tickets]
     for pt in points:
         capi.check(lib, lib.kr_synchronize(pt["stream"]), "sync")

@@ -142,3 +142,43 @@ def test_list_overflow_goes_to_the_ordinary_strict_launch(krlib):
         assert same_bits(got, want)
     finally:
         b.free()
+
+
+def test_batch_of_traces_equals_the_single_calls(krlib):
+    """kr_trace_batch_async_f64 (front halves of all traces first): RK45 points of different tolerance on a small grid -- strict
+    traces below the split threshold are split in a batch -- give exactly what one kr_trace_dev_f64 call each gives."""
+    lib = krlib
+    spec = bench.make_spec(capi, 0.02)
+    tols = [1e-6, 1e-8, 1e-10]
+    bufs = [DeviceRays(lib, spec) for _ in tols]
+    params = []
+    for tol in tols:
+        p = capi.default_params(bench.SPIN)
+        p.integrator, p.r_max, p.rk45_tol = capi.RK45, bench.R_MAX, tol
+        params.append(p)
+    streams = []
+    try:
+        want, want_st = [], []
+        for b, p in zip(bufs, params):
+            b.init()
+            want_st.append(api.trace_dev(p, b.d.value, b.n))
+            want.append(b.fetch())
+        assert all(st["rays_strict_side"] == 0 for st in want_st) and bufs[0].n < (1 << 18)      # single launches when called one by one
+        for _ in bufs:
+            s = C.c_void_p()
+            capi.check(lib, lib.kr_stream_create(C.byref(s)), "stream")
+            streams.append(s)
+        for b, s in zip(bufs, streams):
+            b.init(s.value)
+        tickets = api.trace_batch_async(params, [b.d.value for b in bufs], [b.n for b in bufs], [s.value for s in streams])
+        stats = [api.trace_wait(t) for t in tickets]
+        for b, w, st, wst in zip(bufs, want, stats, want_st):
+            assert st["rays_strict_side"] > 0                     # split in the batch ...
+            assert same_bits(b.fetch(), w)                        # ... with the bits of the single launch
+            for k in ("rays_traced", "steps_total", "rk45_attempts", "rk45_rejects"):
+                assert st[k] == wst[k], k
+    finally:
+        for s in streams:
+            lib.kr_stream_destroy(s)
+        for b in bufs:
+            b.free()

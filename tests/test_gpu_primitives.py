@@ -130,3 +130,20 @@ def test_fifth_root_of_the_step_controller(krlib):
     assert np.array_equal(fac(got[~inside]), fac(x[~inside] ** 0.2))          # 0.1 or 5 either way
     assert np.isnan(probe(18, np.array([np.nan]))[0])
     assert probe(18, np.array([1.0]))[0] == 1.0 and abs(probe(18, np.array([32.0]))[0] - 32.0 ** 0.2) <= 4.5e-16
+
+
+def test_replayed_additions_equal_the_loop(krlib):
+    """kr_replay_additions on the device (the RK45 fixed-point replay's t and phi): 20 000 additions in closed form against numpy
+    doing them one at a time -- increments from far below an ulp (absorbed) to a few per cent of x, both directions, ties."""
+    rng = np.random.default_rng(19)
+    n = 8192
+    x = rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 6, n)
+    dx = x * 2.0 ** -rng.uniform(5, 70, n) * rng.choice([-1.0, 1.0], n)
+    u = np.spacing(np.abs(x[:512]))
+    dx[:512] = (rng.integers(0, 32, 512) + 0.5) * u * rng.choice([-1.0, 1.0], 512)        # exact ties
+    dx[512:600] = 0.0
+    got = probe(19, x, dx)
+    want = x.copy()
+    for _ in range(20000):
+        want = want + dx
+    assert (got.view(np.int64) == want.view(np.int64)).all()
