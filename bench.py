@@ -24,6 +24,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# overlapping launches need hardware queues of their own (raytrace_cpu_amd/csrc/kr_capi.hip); must be set before the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 

@@ -43,6 +43,16 @@ int arith_probe_dev(int op, const double* a, const double* b, double* out, int64
 
 static thread_local std::string g_error;
 
+// Traces are meant to overlap (per-call workspaces, kr_trace_batch_async_f64): each one uses two streams, and a multi-launch driver
+// keeps many in flight.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues per device -- 4 by default -- and a
+// queue runs its kernels in order, so with more streams than queues a 0.4-s side launch holds up whatever else landed behind it:
+// 18 concurrent RK45 sweep points take 1.65 s on 4 queues, 0.99 s on 8, 0.76 s on 16, 0.67 s on 32 (profiles/r02_hw_queues.txt).
+// The variable is read when the runtime initialises, so it is set when this library is loaded, unless the user has chosen a value.
+__attribute__((constructor)) static void more_hardware_queues()
+{
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
+
 void set_error(const std::string& msg) { g_error = msg; }
 
 int hip_fail(hipError_t e, const char* what, const char* file, int line)

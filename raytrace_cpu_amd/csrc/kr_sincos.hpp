@@ -72,6 +72,18 @@ KR_SC_FN void kr_sincos_small_f64(double x, double& s, double& c)
 
 KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c);
 
+// |x| >= 1024 and non-finite arguments (never reached by a healthy ray): the library routine, OUT OF LINE.  Inlined it is ~1 KB of
+// Payne-Hanek code per call site -- 9 KB of the RK45 kernels, 4 KB of the RK4 ones -- and the instruction cache (64 KB per two CUs)
+// is what a lone strict wave and the main launch's waves on the same CUs compete for.
+#ifndef KR_LIBM_OUT_OF_LINE
+#define KR_LIBM_OUT_OF_LINE 1
+#endif
+#if defined(__HIPCC__) && KR_LIBM_OUT_OF_LINE
+static __device__ __attribute__((noinline)) void kr_sincos_libm_f64(double x, double* s, double* c) { sincos(x, s, c); }
+#else
+KR_SC_FN void kr_sincos_libm_f64(double x, double* s, double* c) { sincos(x, s, c); }
+#endif
+
 KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
 {
 #if KR_SMALL_ANGLE_SINCOS && KR_COMPACT_SINCOS
@@ -102,7 +114,7 @@ KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
 #if KR_COMPACT_SINCOS
     const double ax = __builtin_fabs(x);
     if (__builtin_expect(!(ax < 1024.0), 0)) {
-        sincos(x, &s, &c);
+        kr_sincos_libm_f64(x, &s, &c);
         return;
     }
     const double t = __builtin_rint(x * 6.36619772367581382433e-01);        // 2/pi

@@ -8,6 +8,7 @@ one ray buffer each (kr_trace_async_f64 / kr_trace_wait): their long-ray tails o
 more than its slowest point ("concurrent" in the output).
 usage: rk45_tol_sweep.py [hybrid|strict|fast]"""
 import ctypes as C, json, math, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "40")     # 18 traces x 2 streams in flight: one hardware queue each (read when the HIP runtime starts)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import bench
@@ -103,6 +104,7 @@ for pt, st in zip(points, stats):
     hist_ok = hist_ok and hh[-1] > 0 and st["steps_total"] == [r for r in out["runs"] if r["integrator"] == "rk45" and r["h"] == pt["h"] and r["tol"] == pt["tol"]][0]["steps"]
 out["concurrent"] = {"points": len(points), "wall_ms_rounds": walls, "wall_ms": min(walls), "slowest_single_point_ms": max(serial.values()), "sum_of_single_points_ms": sum(serial.values()),
                      "wall_over_slowest_point": min(walls) / max(serial.values()), "per_point_span_ms": [st["kernel_ms"] for st in stats],
+                     "per_point_strict_side_ms": [st["strict_side_ms"] for st in stats], "per_point_main_ms": [st["main_ms"] for st in stats],
                      "same_step_totals_as_point_by_point": bool(hist_ok)}
 for pt in points:
     lib.kr_free(pt["d_rays"]); lib.kr_free(pt["d_hist"]); lib.kr_stream_destroy(pt["stream"])
