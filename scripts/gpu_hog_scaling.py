@@ -15,14 +15,14 @@ spec.beta0, spec.betamax, spec.dbeta = -math.pi, math.pi, 0.01
 n = api.pointsource_count(spec)[0]
 flags = {"hybrid": capi.FLAG_HYBRID, "strict": 0}[sys.argv[1] if len(sys.argv) > 1 else "hybrid"]
 p = capi.default_params(bench.SPIN); p.integrator, p.flags = capi.RK45, flags
-KMAX = 24
+KMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 bufs, streams = [], []
 for _ in range(KMAX):
     d, s = vp(), vp()
     capi.check(lib, lib.kr_malloc(C.byref(d), n * 144), "malloc"); capi.check(lib, lib.kr_stream_create(C.byref(s)), "stream")
     bufs.append(d); streams.append(s)
 out = {}
-for K in (1, 2, 4, 8, 16, 24, 1):
+for K in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2,4,8,16,24,1".split(","))]:
     best = None
     for rep in range(2):
         for d, s in zip(bufs[:K], streams[:K]):
