@@ -26,6 +26,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
+#include <map>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -322,7 +324,7 @@ struct Workspace {
     int* list = nullptr;                         // device: kListCap ray indices
     unsigned char* mask = nullptr;               // device: one byte per ray
     int64_t mask_capacity = 0;
-    hipStream_t side_stream = nullptr;
+    hipStream_t side_stream = nullptr;                   // the second stream of a split trace: belongs to the caller's stream (side_stream_for)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;             // the whole trace, caller's stream
     hipEvent_t ev_strict0 = nullptr, ev_strict1 = nullptr; // strict side (+ overflow) launch, caller's stream
     hipEvent_t ev_main0 = nullptr, ev_main1 = nullptr;     // main launch of a split, side stream
@@ -336,6 +338,37 @@ struct Workspace {
 std::mutex g_mu;
 std::vector<Workspace*> g_pool[64];
 constexpr size_t kMaxPool = 64;
+
+// The second stream of a split trace is a property of the CALLER's stream, not of the call: traces issued on one stream run one after
+// the other anyway, so they can share it, and a driver with 8 streams and 30 tickets outstanding then holds 16 streams, not 38 --
+// beyond ~16 streams in a process the strict side launches slow down (profiles/r02_hw_queues.txt).
+// It must not share a hardware queue with the caller's stream, or the two launches of a split serialise (seen once a process also
+// holds RCCL's streams: HIP multiplexes streams onto a few queues per priority level).  A different priority level has queues of
+// its own; the main launch it carries is also the one that may wait.
+std::map<std::pair<int, hipStream_t>, hipStream_t> g_side_streams;
+
+int side_stream_for(int dev, hipStream_t user, hipStream_t* out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_side_streams.find({dev, user});
+    if (it == g_side_streams.end()) {
+        if (g_side_streams.size() >= 64) {                 // a process that keeps making streams: share what exists
+            it = g_side_streams.begin();
+            std::advance(it, (size_t) (((uintptr_t) user) >> 8) % g_side_streams.size());
+            *out = it->second;
+            return KR_OK;
+        }
+        int least = 0, greatest = 0;
+        KR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        int prio = least;
+        if (const char* e = getenv("KR_SIDE_STREAM_PRIORITY")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "default") ? 0 : least;
+        hipStream_t s = nullptr;
+        KR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+        it = g_side_streams.emplace(std::make_pair(dev, user), s).first;
+    }
+    *out = it->second;
+    return KR_OK;
+}
 
 int workspace_create(int dev, Workspace** out)
 {
@@ -354,16 +387,6 @@ int workspace_create(int dev, Workspace** out)
     KR_WS(hipEventCreate(&w->ev_main1));
     KR_WS(hipEventCreateWithFlags(&w->ev_classified, hipEventDisableTiming));
     KR_WS(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
-    {
-        // The side stream must not share a hardware queue with the caller's stream, or the two launches of a split
-        // serialise (seen once a process also holds RCCL's streams: HIP multiplexes streams onto a few queues per priority
-        // level).  A different priority level has queues of its own; the main launch it carries is also the one that may wait.
-        int least = 0, greatest = 0;
-        KR_WS(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        int prio = least;
-        if (const char* e = getenv("KR_SIDE_STREAM_PRIORITY")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "default") ? 0 : least;
-        KR_WS(hipStreamCreateWithPriority(&w->side_stream, hipStreamNonBlocking, prio));
-    }
     hipDeviceProp_t prop;
     KR_WS(hipGetDeviceProperties(&prop, dev));
 #undef KR_WS
@@ -661,7 +684,11 @@ int trace_front(Pending& t, bool batch)
     t.split = t.hybrid || isolate;
     KR_HIP(hipMemsetAsync(ws->counters, 0, kCounterBlocks * kCounters * sizeof(unsigned long long), t.stream));
     KR_HIP(hipEventRecord(ws->ev0, t.stream));
-    if (t.split) return split_front(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream);
+    if (t.split) {
+        rc = side_stream_for(ws->device, t.stream, &ws->side_stream);
+        if (rc != KR_OK) return rc;
+        return split_front(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream);
+    }
     return KR_OK;
 }
 
