@@ -342,14 +342,15 @@ class ReturnRadiationWorkload:
             self.specs.append(s)
         self.counts = [api.pointsource_count(s)[0] for s in self.specs]
         self.n = max(self.counts)
-        self.nstreams, self.streams, self.buffers, self.order, self.ordered = max(1, args.streams), None, None, None, False
+        self.nstreams, self.streams, self.buffers, self.order, self.ordered = max(0, args.streams), None, None, None, False
         self.p = capi.default_params(SPIN)
         self.p.integrator, self.p.r_max = self.method, 1.1 * R_MAX
         self.result_words = 4 * self.nr
         self.describe = (f"disc->disc returning radiation: {self.nr} source radii r_isco..500 x ~{int(rays)} rays (beta in [0,pi)), {args.integrator.upper()}, "
                          f"r_max=1.1*r_esc, per-radius relaunch (BASELINE configs[4])")
-        self.pipeline = (f"per radius: [pointsource_init+redshift_start]+trace+range_phi+return_classification; radii round-robin over {self.nstreams} stream(s), "
-                         "longest launches first, one counter read-back at the end")
+        self.pipeline = ("per radius: [pointsource_init+redshift_start]+trace+range_phi+return_classification; " +
+                         (f"radii round-robin over {self.nstreams} stream(s), longest launches first, one counter read-back at the end" if self.nstreams else
+                          "all radii resident, traced by ONE merged batch (one side launch + one main launch over all radii)"))
         self.sharding = f"radii cyclic over {world} rank(s), " + ("fixed set of radii (strong scaling)" if args.scaling == "strong" else "radii added with the rank count (weak scaling)")
 
     def step(self, d_rays, d_res, stream):
@@ -358,6 +359,8 @@ class ReturnRadiationWorkload:
         once, after the last radius (kr_trace_async / kr_trace_wait).  --streams 1 is the old serial relaunch loop."""
         import torch
         lib, capi, vp = self.lib, self.capi, C.c_void_p
+        if self.nstreams == 0:
+            return self.step_merged(d_rays, d_res, stream)
         if self.streams is None:
             self.streams = [torch.cuda.Stream() for _ in range(self.nstreams)] if self.nstreams > 1 else []
             self.buffers = [torch.empty(self.n * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda") for _ in self.streams]
@@ -406,6 +409,40 @@ class ReturnRadiationWorkload:
             self.ordered = True
         return tot
 
+    def step_merged(self, d_rays, d_res, stream):
+        """--streams 0: every radius keeps its own ray buffer in HBM (100 x 144 MB = 14.4 GB of 288) and the whole sweep over radii is
+        ONE kr_trace_batch_async_f64 call -- one classification per radius, then one side launch and one main launch over all of them
+        (trace_multi_kernel) -- on one stream; the per-radius classification passes follow."""
+        import torch
+        lib, capi, vp = self.lib, self.capi, C.c_void_p
+        if self.buffers is None:
+            self.buffers = [torch.empty(c * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda") for c in self.counts]
+        cur = torch.cuda.current_stream()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record(cur)
+        for j, s in enumerate(self.specs):
+            capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(s), 0, 1, s.V, 0, 0, vp(self.buffers[j].data_ptr()), self.counts[j], vp(stream)), "init+redshift_start (fused)")
+        tickets = self.api.trace_batch_async([self.p] * len(self.specs), [b.data_ptr() for b in self.buffers], self.counts, [stream] * len(self.specs))
+        for j, ((ir, r_s), s) in enumerate(zip(self.radii, self.specs)):
+            rays_k, n = self.buffers[j].data_ptr(), self.counts[j]
+            capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(rays_k), n, vp(stream)), "range_phi")
+            b = capi.ReturnBins()
+            b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, r_s, 1.5707
+            b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
+            capi.check(lib, lib.kr_reduce_return_dev_f64(C.byref(b), vp(rays_k), n, vp(d_res + 32 * ir), vp(stream)), "reduce")
+        t1.record(cur)
+        tot = None
+        for t in tickets:
+            st = self.api.trace_wait(t)
+            if tot is None:
+                tot = dict(st)
+            else:
+                for key in ("rays_traced", "steps_total", "rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "rk45_extrapolated_steps"):
+                    tot[key] += st[key]
+        t1.synchronize()
+        tot["kernel_ms"] = t0.elapsed_time(t1)
+        return tot
+
     def summary(self, h):
         t = h.reshape(self.nr, 4)
         with np.errstate(invalid="ignore", divide="ignore"):
@@ -426,7 +463,7 @@ def main():
     ap.add_argument("--image-exchange", default="gather", choices=["gather", "allreduce"],
                     help="imageplane, N > 1: gather = pixel-column-cyclic shards, planes collected on rank 0; allreduce = ray-cyclic shards, planes summed everywhere")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: run the exchange on the compute stream instead of beside the next pass")
-    ap.add_argument("--streams", type=int, default=4, help="return_radiation: HIP streams the per-radius launches are spread over (1 = serial relaunch)")
+    ap.add_argument("--streams", type=int, default=0, help="return_radiation: HIP streams the per-radius launches are spread over (1 = serial relaunch; 0 = all radii resident, one merged batch)")
     ap.add_argument("--rays", type=float, default=0, help="rays per GPU (default: 1e7 emissivity = BASELINE configs[1]; 4097^2 imageplane = configs[3])")
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])
     ap.add_argument("--arithmetic", default="auto", choices=["auto", "hybrid", "strict", "fast"],

@@ -230,14 +230,19 @@ int kr_trace_dev_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, 
 int kr_trace_dev_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, kr_stats* stats);
 /* The same trace in two halves, for callers that want the counters of overlapping launches: kr_trace_async_* enqueues and
  * returns a ticket at once; kr_trace_wait blocks until THAT trace has finished, fills *stats (may be NULL) and retires the
- * ticket; kr_trace_release retires it without waiting.  Every ticket must go to exactly one of the two (at most 64 may be
+ * ticket; kr_trace_release retires it without waiting.  Every ticket must go to exactly one of the two (at most 512 may be
  * outstanding per device).  kr_trace_dev_*(.., stats) == async + wait;  (.., NULL) == async + release. */
 int kr_trace_async_f64(const kr_params* p, void* d_rays, int64_t n, void* stream, void** ticket);
 int kr_trace_async_f32(const kr_params* p, void* d_rays, int64_t n, void* stream, void** ticket);
-/* `count` traces at once (one per tolerance of a sweep, per source radius, ...), each on its own stream and ray buffer: the strict
- * side launches of ALL of them -- the few waves that carry each launch's longest rays -- are enqueued before any main launch, so they
- * are placed while the chip is empty and the tails run side by side; strict traces are split whatever their size (>= 4096 rays).
- * Same results as `count` kr_trace_async_f64 calls, bit for bit.  streams may be NULL (all on the default stream). */
+/* `count` traces at once (one per tolerance of a sweep, per source radius, ...), each with its own ray buffer.  When all of them use the
+ * same kernel instances (same integrator, same kind of stop surface, same arithmetic flags; count <= 256, every n >= 4096) the batch is
+ * MERGED: one classification per trace, then ONE strict side launch and ONE main launch over all traces (every wave serves one of the
+ * traces' queues), on streams[0]; other streams wait for the batch at both ends, so whatever the caller enqueued on streams[i] before
+ * the call is seen and whatever it enqueues afterwards sees trace i's result -- but a merged batch wants ONE stream for all its traces
+ * (18 streams waiting on it cost the 18-point RK45 sweep 2.5-6 s instead of 0.41 s).  Otherwise the strict side
+ * launches of all traces are enqueued before any main launch, each trace on its own stream.  Strict traces are split whatever their
+ * size.  Same results and counters as `count` kr_trace_async_f64 calls, bit for bit (kernel_ms etc. then time the whole batch).
+ * streams may be NULL (all on the default stream). */
 int kr_trace_batch_async_f64(int32_t count, const kr_params* const* p, void* const* d_rays, const int64_t* n, void* const* streams, void** tickets);
 int kr_trace_wait(void* ticket, kr_stats* stats);
 int kr_trace_release(void* ticket);

@@ -328,13 +328,14 @@ KR_DEV void momentum_fast_sc(double& pt, double& pr, double& ptheta, double& pph
                              int thetadot_sign, double r, double s, double c, double a, FastAux* aux = nullptr,
                              double* thetadotsq_o = nullptr, double* rdotsq_o = nullptr)
 {
-#pragma clang fp contract(fast)
+    // (every fused multiply-add of the fast path is written out: with "#pragma clang fp contract(fast)" the compiler chose them per
+    // kernel instance, and the same ray came out an ulp apart from the single-trace and the multi-trace kernels)
     const double s2 = s * s;
     const double c2 = c * c;
     const double r2 = r * r;
     const double a2 = a * a;
     const double rhosq = __builtin_fma(a2, c2, r2);
-    const double delta = r2 - 2 * r + a2;
+    const double delta = __builtin_fma(-2.0, r, r2) + a2;
     const double rd = rhosq * delta;
     const double inv = fast_rcp(rd * s2);          // 1 / (rho^2 Delta sin^2)
     const double inv_rd = inv * s2;                // 1 / (rho^2 Delta)
@@ -391,7 +392,6 @@ KR_DEV double sincos_near_limit(double theta0)
 
 KR_DEV void sincos_near(double s0, double c0, double d, double& s, double& c)   // valid for |d| <= sincos_near_limit(theta0)
 {
-#pragma clang fp contract(fast)
     const double d2 = d * d;
     double ps = KR_K(-1.0 / 39916800.0);
     ps = __builtin_fma(ps, d2, KR_K(1.0 / 362880.0));
@@ -412,7 +412,6 @@ KR_DEV void sincos_near(double s0, double c0, double d, double& s, double& c)   
 // k1 with the turning-point logic (see k1_with_flips) on the fast path
 KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
 {
-#pragma clang fp contract(fast)
     const double r = s.r, theta = s.theta, k = s.k, h = s.h;
     double sn, c;
     kr_sincos_fast_f64(theta, sn, c);   // (carrying sin/cos from step to step by angle addition was measured 6 % SLOWER)
@@ -421,7 +420,7 @@ KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
     const double r2 = r * r;
     const double a2 = a * a;
     const double rhosq = __builtin_fma(a2, c2, r2);
-    const double delta = r2 - 2 * r + a2;
+    const double delta = __builtin_fma(-2.0, r, r2) + a2;
     const double rd = rhosq * delta;
     const double inv = fast_rcp(rd * s2);
     const double inv_rd = inv * s2;

@@ -132,12 +132,23 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 #endif
 #define KR_HOG_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? 3 : METHOD == KR_RK45 ? 2 : 1, HOG ? KR_HOG_MAX_WAVES : 8)))
 #endif
+// everything one trace launch works on; a batch of traces hands the kernel an array of these (trace_multi_kernel)
+template <typename T> struct TraceDesc {
+    typename RayOf<T>::type* rays;
+    long long n;
+    TraceConsts<T> c;
+    unsigned long long* counters;
+    const int* list;
+    const unsigned long long* n_ptr;
+    const unsigned char* mask;
+    int n_mode, mask_want;
+};
+
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_HOG_ATTR
-trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
-             const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want)
+KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, const TraceConsts<T>& c, unsigned long long* __restrict__ counters,
+                       const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want,
+                       int& has_prio)
 {
-    if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
     if (n_ptr) {
         // the item count was produced on the device (classify_kernel) and never visits the host:
         // n_mode 1: the first min(n, *n_ptr) list entries;  n_mode 2: all n slots, but only if the list overflowed (else nothing)
@@ -154,7 +165,6 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     unsigned long long my_steps = 0, my_traced = 0;
     uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
 #if KR_LONG_RAY_PRIO
-    int has_prio = 0;
     unsigned prio_tick = 0;
 #endif
 
@@ -265,6 +275,35 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     }
 }
 
+template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
+__global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_HOG_ATTR
+trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
+             const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want)
+{
+    if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
+    int has_prio = 0;
+    trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(rays, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio);
+}
+
+// ONE grid over MANY traces (kr_trace_batch_async_f64 when all traces of the batch use the same kernel instances).  Every wave serves
+// ONE trace -- wave_trace[workgroup index], or workgroup index mod n_desc when no table is given -- with the persistent loop above,
+// and leaves when that trace's queue is exhausted and its own lanes have drained.  The table interleaves the traces in proportion to
+// their ray counts and the grid is larger than what is resident, so that waves of later workgroups move in wherever earlier ones have
+// left: traces balance at wave granularity, a trace's tail is covered by the other traces' work, and the whole batch is two or three
+// launches on two streams whatever the number of traces (beyond ~16 streams per process side launches slow down,
+// profiles/r02_hw_queues.txt).  (A first version let each wave walk through all traces in turn: every wave then paid the tail of one
+// long ray PER TRACE, 2.9 s for the 18-point sweep instead of 0.6 s.)  Per-ray arithmetic is the single-trace kernel's: same bits.
+template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
+__global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_HOG_ATTR
+trace_multi_kernel(const TraceDesc<T>* __restrict__ descs, int n_desc, const int* __restrict__ wave_trace)
+{
+    if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
+    int has_prio = 0;
+    const int ti = wave_trace ? wave_trace[blockIdx.x] : (int) (blockIdx.x % (unsigned) n_desc);
+    const TraceDesc<T>* d = &descs[ti];                           // wave-uniform: scalar loads
+    trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(d->rays, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio);
+}
+
 // ---- hybrid path: which rays must be integrated with the reference's exact arithmetic? ----------------------------
 // A ray is ILL-CONDITIONED when its polar motion or its axial angular momentum is a cancellation residue:
 //   thetadot^2 rho^4 = Q + (k a cos + h cos/sin)(k a cos - h cos/sin)  with |sum| <= 1e-9 (|Q| + |product|), or |h| < 1e-13
@@ -329,6 +368,9 @@ struct Workspace {
     hipEvent_t ev_strict0 = nullptr, ev_strict1 = nullptr; // strict side (+ overflow) launch, caller's stream
     hipEvent_t ev_main0 = nullptr, ev_main1 = nullptr;     // main launch of a split, side stream
     hipEvent_t ev_classified = nullptr, done = nullptr;
+    hipEvent_t ev_in = nullptr;                          // merged batch: the caller's stream of this trace has reached the batch call
+    void* d_descs = nullptr;                             // merged batch (held by its first trace): 3 x kMaxBatch descriptors on the device ...
+    void* h_descs = nullptr;                             // ... and their pinned staging copy
     bool leased = false;       // a caller holds it (between trace_async and trace_wait / trace_release)
     bool pending = false;      // `done` has been recorded and not yet seen complete
     bool split = false;        // the last call used the split path (ev_strict*/ev_main* are valid)
@@ -337,7 +379,9 @@ struct Workspace {
 
 std::mutex g_mu;
 std::vector<Workspace*> g_pool[64];
-constexpr size_t kMaxPool = 64;
+constexpr size_t kMaxPool = 512;
+constexpr int kMaxBatch = 256;                           // traces one merged batch can hold
+constexpr int kMaxMultiGrid = 32768;                     // single-wave workgroups of a merged main launch (wave -> trace table entries)
 
 // The second stream of a split trace is a property of the CALLER's stream, not of the call: traces issued on one stream run one after
 // the other anyway, so they can share it, and a driver with 8 streams and 30 tickets outstanding then holds 16 streams, not 38 --
@@ -387,6 +431,7 @@ int workspace_create(int dev, Workspace** out)
     KR_WS(hipEventCreate(&w->ev_main1));
     KR_WS(hipEventCreateWithFlags(&w->ev_classified, hipEventDisableTiming));
     KR_WS(hipEventCreateWithFlags(&w->done, hipEventDisableTiming));
+    KR_WS(hipEventCreateWithFlags(&w->ev_in, hipEventDisableTiming));
     hipDeviceProp_t prop;
     KR_WS(hipGetDeviceProperties(&prop, dev));
 #undef KR_WS
@@ -527,6 +572,31 @@ int launch_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, const TraceConst
         default:
             return dest ? launch<double, KR_RK45, true, FAST, HOG>(rays, n, c, counters, cus, stream, mb, la)
                         : launch<double, KR_RK45, false, FAST, HOG>(rays, n, c, counters, cus, stream, mb, la);
+    }
+}
+
+// the same two for a whole batch of traces in ONE launch (trace_multi_kernel): `grid` single-wave workgroups, wave -> trace by table or modulo
+template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG>
+int launch_multi(const TraceDesc<T>* d_descs, int n_desc, const int* d_wave_trace, int grid, hipStream_t stream)
+{
+    constexpr int kRefill = KR_REFILL_MIN;
+    auto kern = trace_multi_kernel<T, METHOD, USE_DEST, FAST, HOG, kRefill>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTraceBlock), 0, stream, d_descs, n_desc, d_wave_trace);
+    KR_HIP(hipGetLastError());
+    return KR_OK;
+}
+
+template <bool FAST, bool HOG>
+int launch_multi_f64(int integrator, bool dest, const TraceDesc<double>* d, int n_desc, const int* wt, int grid, hipStream_t stream)
+{
+    switch (integrator) {
+        case KR_EULER: return launch_multi<double, KR_EULER, false, FAST, HOG>(d, n_desc, wt, grid, stream);
+        case KR_RK4:
+            return dest ? launch_multi<double, KR_RK4, true, FAST, HOG>(d, n_desc, wt, grid, stream)
+                        : launch_multi<double, KR_RK4, false, FAST, HOG>(d, n_desc, wt, grid, stream);
+        default:
+            return dest ? launch_multi<double, KR_RK45, true, FAST, HOG>(d, n_desc, wt, grid, stream)
+                        : launch_multi<double, KR_RK45, false, FAST, HOG>(d, n_desc, wt, grid, stream);
     }
 }
 
@@ -744,7 +814,123 @@ int trace_async(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream,
     return KR_OK;
 }
 
-// The same for `count` traces at once (double precision), front halves first.  On failure nothing is left outstanding.
+// A batch whose traces all run the same kernel instances (same integrator, same kind of stop surface, same arithmetic mode) is
+// MERGED: one classification per trace, then ONE side launch, ONE main launch (and one overflow launch) over all of them
+// (trace_multi_kernel), on the first trace's stream and its second stream; every other trace's stream waits for the batch at both ends.
+int merged_batch(std::vector<Pending>& ts, bool hybrid)
+{
+    const int count = (int) ts.size();
+    const kr_params* p0 = ts[0].p;
+    const bool dest = p0->stop_kind != KR_STOP_THETA;
+    hipStream_t primary = ts[0].stream;
+    for (auto& t : ts) {
+        t.steplim = (t.p->steplim > 0) ? t.p->steplim : (t.p->integrator == KR_RK45) ? KR_RK45_STEPLIM : KR_STEPLIM;
+        int rc = workspace_acquire(&t.ws);
+        if (rc != KR_OK) return rc;
+        t.ws->split = true;
+        t.ws->n = t.n;
+        t.hybrid = hybrid;
+        t.split = true;
+    }
+    Workspace* w0 = ts[0].ws;
+    hipStream_t side = nullptr;
+    int rc = side_stream_for(w0->device, primary, &side);
+    if (rc != KR_OK) return rc;
+    const size_t desc_bytes = sizeof(TraceDesc<double>);
+    const size_t table_off = 3 * kMaxBatch * desc_bytes;                   // [side descs | main descs | overflow descs | wave -> trace table of the main launch]
+    const size_t staging_bytes = table_off + kMaxMultiGrid * sizeof(int);
+    if (!w0->d_descs) {
+        KR_HIP(hipMalloc(&w0->d_descs, staging_bytes));
+        KR_HIP(hipHostMalloc(&w0->h_descs, staging_bytes, hipHostMallocDefault));
+    }
+    // inputs: whatever the callers enqueued on the traces' own streams (their ray sources) comes first
+    for (auto& t : ts)
+        if (t.stream != primary) {
+            KR_HIP(hipEventRecord(t.ws->ev_in, t.stream));
+            KR_HIP(hipStreamWaitEvent(primary, t.ws->ev_in, 0));
+        }
+    TraceDesc<double>* h = (TraceDesc<double>*) w0->h_descs;
+    TraceDesc<double>* hog = h, * mainv = h + kMaxBatch, * rest = h + 2 * kMaxBatch;
+    int n_rest = 0;
+    int64_t hog_max = 1, main_waves = 0, n_total = 0;
+    for (int i = 0; i < count; i++) {
+        Pending& t = ts[i];
+        Workspace* ws = t.ws;
+        ws->side_stream = side;
+        if (t.n > 0x7fffffff) { set_error("kr_trace: the split path indexes rays with 32 bits"); return KR_EINVAL; }
+        if (ws->mask_capacity < t.n) {
+            if (ws->mask) KR_HIP(hipFree(ws->mask));
+            ws->mask = nullptr;
+            ws->mask_capacity = 0;
+            KR_HIP(hipMalloc((void**) &ws->mask, (size_t) t.n));
+            ws->mask_capacity = t.n;
+        }
+        KR_HIP(hipMemsetAsync(ws->counters, 0, kCounterBlocks * kCounters * sizeof(unsigned long long), primary));
+        KR_HIP(hipEventRecord(ws->ev0, primary));
+        unsigned long long* split_words = ws->counters + 3 * kCounters;
+        const int cgrid = (int) ((t.n + kBlock - 1) / kBlock);
+        hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, primary, (const kr_ray_f64*) t.d_rays, (long long) t.n, t.p->spin, ws->mask, ws->list, split_words + 1);
+        KR_HIP(hipGetLastError());
+        const TraceConsts<double> c = make_consts<double>(t.p, t.steplim);
+        const int64_t list_max = std::min<int64_t>(t.n, kListCap);
+        hog[i] = TraceDesc<double>{(kr_ray_f64*) t.d_rays, (long long) list_max, c, ws->counters + kCounters, ws->list, split_words + 1, nullptr, 1, 0};
+        mainv[i] = TraceDesc<double>{(kr_ray_f64*) t.d_rays, (long long) t.n, c, ws->counters, nullptr, nullptr, ws->mask, 0, 0};
+        if (t.n > kListCap) rest[n_rest++] = TraceDesc<double>{(kr_ray_f64*) t.d_rays, (long long) t.n, c, ws->counters + 2 * kCounters, nullptr, split_words + 1, ws->mask, 2, 2};
+        hog_max = std::max<int64_t>(hog_max, (list_max + kTraceBlock - 1) / kTraceBlock);
+        main_waves += (t.n + kTraceBlock - 1) / kTraceBlock;
+        n_total += t.n;
+    }
+    // main launch: twice what is resident (3 waves per SIMD), never more waves than 64-ray loads; wave -> trace in proportion to the
+    // traces' ray counts, interleaved so that the first waves to be placed cover every trace
+    const int mb = KR_FLAG_GET_BLOCKS_PER_CU(p0->flags);
+    const int64_t resident = (int64_t) w0->cus * 4 * (mb ? mb : 3);
+    const int main_grid = (int) std::max<int64_t>(count, std::min<int64_t>({main_waves, 2 * resident, (int64_t) kMaxMultiGrid}));
+    int* wave_trace = (int*) ((char*) w0->h_descs + table_off);
+    {
+        std::vector<std::pair<double, int>> order;
+        order.reserve((size_t) main_grid + (size_t) count);
+        for (int i = 0; i < count; i++) {
+            const int64_t q = std::max<int64_t>(1, (int64_t) ((double) (main_grid - count) * (double) ts[i].n / (double) n_total) + 1);
+            for (int64_t k = 0; k < q; k++) order.emplace_back(((double) k + 0.5) / (double) q + 1e-9 * i, i);
+        }
+        std::sort(order.begin(), order.end());
+        for (int b = 0; b < main_grid; b++) wave_trace[b] = order[(size_t) b % order.size()].second;     // (quotas sum to main_grid up to rounding)
+    }
+    KR_HIP(hipMemcpyAsync(w0->d_descs, w0->h_descs, staging_bytes, hipMemcpyHostToDevice, primary));
+    const TraceDesc<double>* d = (const TraceDesc<double>*) w0->d_descs;
+    const int* d_wave_trace = (const int*) ((const char*) w0->d_descs + table_off);
+    KR_HIP(hipEventRecord(w0->ev_classified, primary));
+    for (auto& t : ts) KR_HIP(hipEventRecord(t.ws->ev_strict0, primary));
+    // side launch (wave -> trace by modulo): as many waves per trace as its list could need, but no more than fit on the chip at once
+    // in total (1024 SIMDs; at least 4 per trace) -- a wave refills from its trace's list, so fewer waves only mean more rays per wave,
+    // whereas thousands of exclusive single-wave workgroups that find nothing to do still have to be placed one by one
+    const int64_t hog_per_trace = std::max<int64_t>(4, std::min<int64_t>(hog_max, (4 * (int64_t) w0->cus) / count));
+    rc = launch_multi_f64<false, true>(p0->integrator, dest, d, count, nullptr, (int) (hog_per_trace * count), primary);
+    if (rc != KR_OK) return rc;
+    for (auto& t : ts) KR_HIP(hipEventRecord(t.ws->ev_strict1, primary));
+    KR_HIP(hipStreamWaitEvent(side, w0->ev_classified, 0));
+    for (auto& t : ts) KR_HIP(hipEventRecord(t.ws->ev_main0, side));
+    rc = hybrid ? launch_multi_f64<true, false>(p0->integrator, dest, d + kMaxBatch, count, d_wave_trace, main_grid, side)
+                : launch_multi_f64<false, false>(p0->integrator, dest, d + kMaxBatch, count, d_wave_trace, main_grid, side);
+    if (rc != KR_OK) return rc;
+    if (n_rest > 0) {
+        // overflow launch: a no-op unless some trace flagged more rays than its list holds (then: few persistent waves per such trace)
+        rc = launch_multi_f64<false, false>(p0->integrator, dest, d + 2 * kMaxBatch, n_rest, nullptr, (int) std::min<int64_t>((int64_t) n_rest * 64, resident), side);
+        if (rc != KR_OK) return rc;
+    }
+    for (auto& t : ts) KR_HIP(hipEventRecord(t.ws->ev_main1, side));
+    KR_HIP(hipStreamWaitEvent(primary, ts.back().ws->ev_main1, 0));      // the last one recorded: every ev_main1 has completed by then
+    for (auto& t : ts) {
+        Workspace* ws = t.ws;
+        KR_HIP(hipEventRecord(ws->ev1, primary));
+        KR_HIP(hipMemcpyAsync(ws->h_counters, ws->counters, kCounterBlocks * kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, primary));
+        KR_HIP(hipEventRecord(ws->done, primary));
+        if (t.stream != primary) KR_HIP(hipStreamWaitEvent(t.stream, ws->done, 0));       // the caller's next kernels on that stream see the traced rays
+    }
+    return KR_OK;
+}
+
+// The same for `count` traces at once (double precision).  On failure nothing is left outstanding.
 int trace_batch_async(int count, const kr_params* const* p, void* const* d_rays, const int64_t* n, void* const* streams, void** tickets)
 {
     if (count < 0 || (count > 0 && (!p || !d_rays || !n || !tickets))) { set_error("kr_trace_batch_async: null argument"); return KR_EINVAL; }
@@ -754,6 +940,23 @@ int trace_batch_async(int count, const kr_params* const* p, void* const* d_rays,
         ts[i].p = p[i]; ts[i].d_rays = d_rays[i]; ts[i].n = n[i]; ts[i].stream = streams ? (hipStream_t) streams[i] : nullptr;
     }
     int rc = KR_OK;
+    // mergeable: every trace valid, non-empty, split-capable, and on the same kernel instances
+    bool merge = count >= 2 && count <= kMaxBatch && !getenv("KR_NO_MERGED_BATCH") && !getenv("KR_NO_ISOLATE");
+    for (int i = 0; i < count && merge; i++) {
+        if (validate(p[i], d_rays[i], n[i]) != KR_OK || n[i] < 4096 || (p[i]->flags & KR_FLAG_FAST_MATH)) merge = false;
+        else if (p[i]->integrator != p[0]->integrator || (p[i]->stop_kind != KR_STOP_THETA) != (p[0]->stop_kind != KR_STOP_THETA) ||
+                 (p[i]->flags & KR_FLAG_HYBRID) != (p[0]->flags & KR_FLAG_HYBRID) || KR_FLAG_GET_BLOCKS_PER_CU(p[i]->flags) != KR_FLAG_GET_BLOCKS_PER_CU(p[0]->flags))
+            merge = false;
+    }
+    if (merge) {
+        rc = merged_batch(ts, (p[0]->flags & KR_FLAG_HYBRID) != 0);
+        if (rc != KR_OK) {
+            for (auto& t : ts) abandon(t);
+            return rc;
+        }
+        for (int i = 0; i < count; i++) hand_over(ts[i], &tickets[i]);
+        return KR_OK;
+    }
     for (int i = 0; i < count && rc == KR_OK; i++) rc = trace_front(ts[i], true);
     for (int i = 0; i < count && rc == KR_OK; i++) rc = trace_back(ts[i]);
     if (rc != KR_OK) {

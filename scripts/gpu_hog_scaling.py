@@ -14,12 +14,15 @@ spec.cosalpha0, spec.cosalphamax, spec.dcosalpha = -0.995, 0.995, 0.01
 spec.beta0, spec.betamax, spec.dbeta = -math.pi, math.pi, 0.01
 n = api.pointsource_count(spec)[0]
 flags = {"hybrid": capi.FLAG_HYBRID, "strict": 0}[sys.argv[1] if len(sys.argv) > 1 else "hybrid"]
+ONE_STREAM = len(sys.argv) > 4 and sys.argv[4] == "one-stream"      # every copy on the same stream (what a merged batch wants)
 p = capi.default_params(bench.SPIN); p.integrator, p.flags = capi.RK45, flags
 KMAX = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 bufs, streams = [], []
 for _ in range(KMAX):
     d, s = vp(), vp()
-    capi.check(lib, lib.kr_malloc(C.byref(d), n * 144), "malloc"); capi.check(lib, lib.kr_stream_create(C.byref(s)), "stream")
+    capi.check(lib, lib.kr_malloc(C.byref(d), n * 144), "malloc")
+    if not (ONE_STREAM and streams): capi.check(lib, lib.kr_stream_create(C.byref(s)), "stream")
+    else: s = streams[0]
     bufs.append(d); streams.append(s)
 out = {}
 for K in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2,4,8,16,24,1".split(","))]:

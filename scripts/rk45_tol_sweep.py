@@ -3,12 +3,11 @@
 src/tests/emissivity_rk45_plot.cpp:35-38 grid 0.01 x 0.01 = 125 863 allocated rays), source h = 5 (the reference's
 sweep) and h = 10 (BASELINE), on one MI355X through the C ABI.  Prints one JSON document.
 RK4 on the same grid is run beside it so the RK4-vs-RK45 emissivity deviation the reference's sweep plots can be formed.
-After the point-by-point pass, all 18 points (2 heights x 9 tolerances) are run AT ONCE, device-resident, one stream and
-one ray buffer each (kr_trace_async_f64 / kr_trace_wait): their long-ray tails overlap, so the whole sweep should cost little
-more than its slowest point ("concurrent" in the output).
+After the point-by-point pass, all 18 points (2 heights x 9 tolerances) are run AT ONCE, device-resident, one ray buffer each, as ONE
+merged batch on one stream (kr_trace_batch_async_f64: one strict side launch and one main launch over all 18 traces): their long-ray
+tails run side by side, so the whole sweep should cost little more than its slowest point ("concurrent" in the output).
 usage: rk45_tol_sweep.py [hybrid|strict|fast]"""
 import ctypes as C, json, math, os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "40")     # 18 traces x 2 streams in flight: one hardware queue each (read when the HIP runtime starts)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 import bench
@@ -60,6 +59,8 @@ for h in (5.0, 10.0):
 # ---- the same 18 points, all in flight together -------------------------------------------------------------------------
 lib = api.lib()
 vp = C.c_void_p
+ONE_STREAM = vp()
+capi.check(lib, lib.kr_stream_create(C.byref(ONE_STREAM)), "stream")      # a merged batch wants ONE stream (more streams only add queues to schedule)
 points = []
 for h in (5.0, 10.0):
     spec = capi.PointSourceSpec()
@@ -70,10 +71,10 @@ for h in (5.0, 10.0):
     n = api.pointsource_count(spec)[0]
     bins = gc.emis_bins(spec, nr=30)
     for tol in TOLS:
-        d_rays, d_hist, stream = vp(), vp(), vp()
+        d_rays, d_hist = vp(), vp()
         capi.check(lib, lib.kr_malloc(C.byref(d_rays), n * capi.RAY_F64.itemsize), "malloc")
         capi.check(lib, lib.kr_malloc(C.byref(d_hist), (5 * bins.nr + 1) * 8), "malloc")
-        capi.check(lib, lib.kr_stream_create(C.byref(stream)), "stream")
+        stream = ONE_STREAM
         p = capi.default_params(gc.SPIN); p.integrator, p.rk45_tol, p.flags = capi.RK45, tol, ARITH
         points.append(dict(h=h, tol=tol, spec=spec, n=n, bins=bins, d_rays=d_rays, d_hist=d_hist, stream=stream, p=p))
 
@@ -93,8 +94,7 @@ for rnd in range(3):
     for pt in points:
         post(pt)
     stats = [api.trace_wait(t) for t in tickets]
-    for pt in points:
-        capi.check(lib, lib.kr_synchronize(pt["stream"]), "sync")
+    capi.check(lib, lib.kr_synchronize(ONE_STREAM), "sync")
     walls.append(1e3 * (time.perf_counter() - t0))
 serial = {(r["h"], r["tol"]): r["kernel_ms"] for r in out["runs"] if r["integrator"] == "rk45"}
 hist_ok = True
@@ -107,5 +107,6 @@ out["concurrent"] = {"points": len(points), "wall_ms_rounds": walls, "wall_ms": 
                      "per_point_strict_side_ms": [st["strict_side_ms"] for st in stats], "per_point_main_ms": [st["main_ms"] for st in stats],
                      "same_step_totals_as_point_by_point": bool(hist_ok)}
 for pt in points:
-    lib.kr_free(pt["d_rays"]); lib.kr_free(pt["d_hist"]); lib.kr_stream_destroy(pt["stream"])
+    lib.kr_free(pt["d_rays"]); lib.kr_free(pt["d_hist"])
+lib.kr_stream_destroy(ONE_STREAM)
 print(json.dumps(out, indent=1))

@@ -182,3 +182,40 @@ def test_batch_of_traces_equals_the_single_calls(krlib):
             lib.kr_stream_destroy(s)
         for b in bufs:
             b.free()
+
+
+@pytest.mark.parametrize("merged", [True, False])
+@pytest.mark.parametrize("flags,method", [(capi.FLAG_HYBRID, capi.RK4), (0, capi.RK45), (capi.FLAG_HYBRID, capi.EULER)])
+def test_merged_batch_is_bitwise_the_single_traces(krlib, flags, method, merged, monkeypatch):
+    """A batch whose traces share their kernel instances runs as ONE side launch + ONE main launch over all of them
+    (trace_multi_kernel; KR_NO_MERGED_BATCH=1: one pair of launches per trace, front halves first).  Either way every trace gets the
+    bits and the counters of a call of its own -- different sources, sizes and tolerances in one batch, all on one stream."""
+    lib = krlib
+    if not merged:
+        monkeypatch.setenv("KR_NO_MERGED_BATCH", "1")
+    specs = [bench.make_spec(capi, 0.02), bench.make_spec(capi, 0.013), bench.make_spec(capi, 0.03), bench.make_spec(capi, 0.017)]
+    specs[1].pos[1], specs[2].pos[1] = 5.0, 20.0
+    bufs = [DeviceRays(lib, s) for s in specs]
+    params = []
+    for i in range(len(specs)):
+        p = capi.default_params(bench.SPIN)
+        p.integrator, p.r_max, p.flags, p.rk45_tol = method, bench.R_MAX, flags, [1e-6, 1e-8, 1e-7, 1e-9][i]
+        params.append(p)
+    try:
+        want, want_st = [], []
+        for b, p in zip(bufs, params):
+            b.init()
+            want_st.append(api.trace_dev(p, b.d.value, b.n))
+            want.append(b.fetch())
+        for b in bufs:
+            b.init()
+        tickets = api.trace_batch_async(params, [b.d.value for b in bufs], [b.n for b in bufs], None)
+        stats = [api.trace_wait(t) for t in tickets]
+        for b, w, st, wst in zip(bufs, want, stats, want_st):
+            assert same_bits(b.fetch(), w)
+            for k in ("rays_total", "rays_traced", "steps_total", "rk45_attempts", "rk45_rejects", "rk45_stationary_steps", "rk45_extrapolated_steps"):
+                assert st[k] == wst[k], k
+            assert st["rays_strict_side"] > 0
+    finally:
+        for b in bufs:
+            b.free()

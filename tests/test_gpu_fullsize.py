@@ -223,7 +223,8 @@ def test_return_radiation_full_size_properties(krlib):
     """BASELINE configs[4]: 100 source radii x ~1e6 rays, Euler, one launch per radius spread over 4 streams (bench.py's
     ReturnRadiationWorkload, the driver that mirrors src/return_radiation/disc_source_photonfrac_r.cpp:74-135).
       * per radius: return + escape + lost <= ray_count (the classes are disjoint), and within 5 % of it;
-      * the overlapped launches (4 streams, async tickets) give the table of the serial relaunch loop;
+      * the overlapped launches (4 streams, async tickets) and the merged batch (all radii resident, one side + one main launch)
+        give the table of the serial relaunch loop;
       * one radius split into 3 ray-cyclic shards adds up to that radius's row;
       * a sample of one radius's rays equals the oracle's trace of the same records."""
     import types
@@ -261,6 +262,17 @@ def test_return_radiation_full_size_properties(krlib):
     table1 = res.cpu().numpy().reshape(100, 4)
     assert st1["steps_total"] == st["steps_total"] and st1["rays_traced"] == st["rays_traced"]
     np.testing.assert_allclose(table1, table, rtol=1e-11)
+    # ... and all 100 radii resident (14.4 GB), traced by ONE merged batch (bench.py --streams 0, the default): same table again
+    args0 = types.SimpleNamespace(integrator="euler", radii=100, rays=1e6, streams=0, scaling="weak")
+    wl0 = bench.ReturnRadiationWorkload(args0, lib, capi, api, 0, 1)
+    wl0.p.flags = capi.FLAG_HYBRID
+    res.zero_()
+    st0 = wl0.step(rays.data_ptr(), res.data_ptr(), stream)
+    torch.cuda.synchronize()
+    table0 = res.cpu().numpy().reshape(100, 4)
+    assert st0["steps_total"] == st["steps_total"] and st0["rays_traced"] == st["rays_traced"]
+    np.testing.assert_allclose(table0, table, rtol=1e-11)
+    del wl0
     # one radius: shard additivity + sample vs oracle
     j = 37
     spec, r_s = wl.specs[j], wl.radii[j][1]
