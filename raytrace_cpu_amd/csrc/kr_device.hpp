@@ -394,15 +394,15 @@ KR_DEV void sincos_near(double s0, double c0, double d, double& s, double& c)   
 {
     const double d2 = d * d;
     double ps = KR_K(-1.0 / 39916800.0);
-    ps = __builtin_fma(ps, d2, KR_K(1.0 / 362880.0));
-    ps = __builtin_fma(ps, d2, KR_K(-1.0 / 5040.0));
-    ps = __builtin_fma(ps, d2, KR_K(1.0 / 120.0));
-    ps = __builtin_fma(ps, d2, KR_K(-1.0 / 6.0));
+    ps = kr_fma3(ps, d2, KR_K(1.0 / 362880.0));
+    ps = kr_fma3(ps, d2, KR_K(-1.0 / 5040.0));
+    ps = kr_fma3(ps, d2, KR_K(1.0 / 120.0));
+    ps = kr_fma3(ps, d2, KR_K(-1.0 / 6.0));
     const double sd = __builtin_fma(d * d2, ps, d);                 // sin d
     double pc = KR_K(-1.0 / 3628800.0);
-    pc = __builtin_fma(pc, d2, KR_K(1.0 / 40320.0));
-    pc = __builtin_fma(pc, d2, KR_K(-1.0 / 720.0));
-    pc = __builtin_fma(pc, d2, KR_K(1.0 / 24.0));
+    pc = kr_fma3(pc, d2, KR_K(1.0 / 40320.0));
+    pc = kr_fma3(pc, d2, KR_K(-1.0 / 720.0));
+    pc = kr_fma3(pc, d2, KR_K(1.0 / 24.0));
     pc = __builtin_fma(pc, d2, -0.5);
     const double cm = d2 * pc;                                       // cos d - 1
     s = s0 + __builtin_fma(c0, sd, s0 * cm);

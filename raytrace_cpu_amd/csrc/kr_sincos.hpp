@@ -30,6 +30,24 @@ static __device__ __forceinline__ double kr_sconst(double c) { asm volatile("" :
 #else
 #define KR_K(x) (x)
 #endif
+// Horner step p <- fma(z, p, C) as ONE vector instruction.  The compiler keeps the coefficients C resident in VGPR pairs across the
+// step loop (good) but then emits the destructive two-operand form, v_mov_b64 tmp, C + v_fmac_f64 tmp, z, p -- two vector
+// instructions per polynomial step, ~40 per RK4 step of the fast kernel.  Spelling the three-operand v_fma_f64 out keeps C where it is.
+// Same operation, same rounding.
+#ifndef KR_ASM_FMA
+#define KR_ASM_FMA 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && KR_ASM_FMA
+static __device__ __forceinline__ double kr_fma3(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#else
+#define kr_fma3(a, b, c) __builtin_fma((a), (b), (c))
+#endif
+
 #ifndef KR_SGPR_COEFFS_STRICT
 #define KR_SGPR_COEFFS_STRICT 1
 #endif
@@ -64,9 +82,9 @@ static __device__ __forceinline__ double kr_sconst(double c) { asm volatile("" :
 KR_SC_FN void kr_sincos_small_f64(double x, double& s, double& c)
 {
     const double z = x * x;
-    const double ps = __builtin_fma(z, __builtin_fma(z, KR_KS(-1.98412698412698412698e-04), KR_KS(8.33333333333333333333e-03)), KR_KS(-1.66666666666666666667e-01));
+    const double ps = kr_fma3(z, kr_fma3(z, KR_KS(-1.98412698412698412698e-04), KR_KS(8.33333333333333333333e-03)), KR_KS(-1.66666666666666666667e-01));
     s = __builtin_fma(x * z, ps, x);
-    const double pc = __builtin_fma(z, KR_KS(-1.38888888888888888889e-03), KR_KS(4.16666666666666666667e-02));
+    const double pc = kr_fma3(z, KR_KS(-1.38888888888888888889e-03), KR_KS(4.16666666666666666667e-02));
     c = 1.0 + __builtin_fma(z * z, pc, -0.5 * z);
 }
 
@@ -125,12 +143,12 @@ KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
     const double z = r * r;
     // sin(r + y)
     const double v = z * r;
-    const double ps = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, KR_KS(1.58969099521155010221e-10), KR_KS(-2.50507602534068634195e-08)),
-                                                                      KR_KS(2.75573137070700676789e-06)), KR_KS(-1.98412698298579493134e-04)), KR_KS(8.33333333332248946124e-03));
+    const double ps = kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, KR_KS(1.58969099521155010221e-10), KR_KS(-2.50507602534068634195e-08)),
+                                                          KR_KS(2.75573137070700676789e-06)), KR_KS(-1.98412698298579493134e-04)), KR_KS(8.33333333332248946124e-03));
     const double sr = r - ((z * (0.5 * y - v * ps) - y) - v * -1.66666666666666324348e-01);
     // cos(r + y)
-    const double pc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, KR_KS(-1.13596475577881948265e-11), KR_KS(2.08757232129817482790e-09)),
-                                                                                          KR_KS(-2.75573143513906633035e-07)), KR_KS(2.48015872894767294178e-05)), KR_KS(-1.38888888888741095749e-03)), KR_KS(4.16666666666666019037e-02));
+    const double pc = z * kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, KR_KS(-1.13596475577881948265e-11), KR_KS(2.08757232129817482790e-09)),
+                                                                      KR_KS(-2.75573143513906633035e-07)), KR_KS(2.48015872894767294178e-05)), KR_KS(-1.38888888888741095749e-03)), KR_KS(4.16666666666666019037e-02));
     const double ar = __builtin_fabs(r);
     // qx ~ |r|/4 with a short mantissa, so that 1 - qx and z/2 - qx are exact (0 below 0.3, capped at 0.28125)
     const unsigned long long qbits = (__builtin_bit_cast(unsigned long long, ar) - 0x0020000000000000ull) & 0xFFFFFFFF00000000ull;
@@ -166,17 +184,17 @@ KR_SC_FN void kr_sincos_fast_f64(double x, double& s, double& c)
     double r = __builtin_fma(-t, 1.57079632679489655800e+00, x);
     r = __builtin_fma(-t, 6.12323399573676603587e-17, r);
     const double z = r * r;
-    double ps = __builtin_fma(z, KR_K(1.58969099521155010221e-10), KR_K(-2.50507602534068634195e-08));
-    ps = __builtin_fma(z, ps, KR_K(2.75573137070700676789e-06));
-    ps = __builtin_fma(z, ps, KR_K(-1.98412698298579493134e-04));
-    ps = __builtin_fma(z, ps, KR_K(8.33333333332248946124e-03));
-    ps = __builtin_fma(z, ps, KR_K(-1.66666666666666324348e-01));
+    double ps = kr_fma3(z, KR_K(1.58969099521155010221e-10), KR_K(-2.50507602534068634195e-08));
+    ps = kr_fma3(z, ps, KR_K(2.75573137070700676789e-06));
+    ps = kr_fma3(z, ps, KR_K(-1.98412698298579493134e-04));
+    ps = kr_fma3(z, ps, KR_K(8.33333333332248946124e-03));
+    ps = kr_fma3(z, ps, KR_K(-1.66666666666666324348e-01));
     const double sr = __builtin_fma(r * z, ps, r);
-    double pc = __builtin_fma(z, KR_K(-1.13596475577881948265e-11), KR_K(2.08757232129817482790e-09));
-    pc = __builtin_fma(z, pc, KR_K(-2.75573143513906633035e-07));
-    pc = __builtin_fma(z, pc, KR_K(2.48015872894767294178e-05));
-    pc = __builtin_fma(z, pc, KR_K(-1.38888888888741095749e-03));
-    pc = __builtin_fma(z, pc, KR_K(4.16666666666666019037e-02));
+    double pc = kr_fma3(z, KR_K(-1.13596475577881948265e-11), KR_K(2.08757232129817482790e-09));
+    pc = kr_fma3(z, pc, KR_K(-2.75573143513906633035e-07));
+    pc = kr_fma3(z, pc, KR_K(2.48015872894767294178e-05));
+    pc = kr_fma3(z, pc, KR_K(-1.38888888888741095749e-03));
+    pc = kr_fma3(z, pc, KR_K(4.16666666666666019037e-02));
     pc = __builtin_fma(z, pc, -0.5);
     const double cr = __builtin_fma(z, pc, 1.0);
     const bool odd = (n & 1) != 0;
