@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses a gpurun_out/prof_<tag>/ directory (scripts/profile_r01.sh) into profiles/<tag>_*.{csv,json}."""
+"""Condenses a gpurun_out/prof_<tag>/ directory (scripts/profile_round.sh) into profiles/<tag>_*.{csv,json}."""
 import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 src = f"gpurun_out/prof_{tag}"
@@ -7,7 +7,7 @@ os.makedirs("profiles", exist_ok=True)
 ks = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
-summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats / --pmc <group> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (scripts/profile_r01.sh)", "counters_per_trace_kernel_launch": {}}
+summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats / --pmc <group> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (scripts/profile_round.sh)", "counters_per_trace_kernel_launch": {}}
 for d in sorted(glob.glob(f"{src}/pmc_*")):
     fs = glob.glob(f"{d}/*/*_counter_collection.csv")
     if not fs: continue
