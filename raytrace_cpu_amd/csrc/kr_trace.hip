@@ -130,7 +130,10 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 #ifndef KR_HOG_MAX_WAVES
 #define KR_HOG_MAX_WAVES 8   // measured: (1,1) makes the side launch 2 % slower
 #endif
-#define KR_HOG_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? 3 : METHOD == KR_RK45 ? 2 : 1, HOG ? KR_HOG_MAX_WAVES : 8)))
+#ifndef KR_RK4_MIN_WAVES
+#define KR_RK4_MIN_WAVES 3
+#endif
+#define KR_HOG_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? KR_RK4_MIN_WAVES : METHOD == KR_RK45 ? 2 : 1, HOG ? KR_HOG_MAX_WAVES : 8)))
 #endif
 // everything one trace launch works on; a batch of traces hands the kernel an array of these (trace_multi_kernel)
 template <typename T> struct TraceDesc {
