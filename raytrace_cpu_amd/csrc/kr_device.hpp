@@ -195,11 +195,14 @@ template <typename T> struct Lane {
     int32_t creep_run;      // ... and in this many consecutive outer steps before it
     bool creep_mode;        // the rest of the ray is replayed step by step from k1 alone (step_rk45)
     T creep_dt, creep_dphi; // its t and phi increments per step
+    // RK45, strict arithmetic: what the accepted trial's last stage (k7) already knows about the point the next step's k1 is taken at
+    bool fsal_valid;
+    T f_sin2theta, f_rhosq, f_delta, f_pt, f_thetadotsq, f_abs_ptheta;
 };
 
 // momentum_from_consts, src/include/kerr.h:300-335
 template <typename T, bool LEAN>
-KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a)
+KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a, Lane<T>* keep = nullptr)
 {
     T sin_theta, cos_theta;
     kr_sincos(theta, sin_theta, cos_theta);
@@ -216,7 +219,11 @@ KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int r
     const T hcs = dv<LEAN>(h * cos_theta, sin_theta);
     T thetadotsq = Q + (k * a * cos_theta + hcs) * (k * a * cos_theta - hcs);
     thetadotsq = dv<LEAN>(thetadotsq, rhosq * rhosq);
-    ptheta = sq<LEAN>(kr_abs(thetadotsq)) * thetadot_sign;
+    const T abs_ptheta = sq<LEAN>(kr_abs(thetadotsq));
+    ptheta = abs_ptheta * thetadot_sign;
+    if (keep) {      // (see k1_from_last_stage)
+        keep->f_sin2theta = sin2theta; keep->f_rhosq = rhosq; keep->f_delta = delta; keep->f_pt = pt; keep->f_thetadotsq = thetadotsq; keep->f_abs_ptheta = abs_ptheta;
+    }
 
     T rdotsq = k * pt - h * pphi - rhosq * ptheta * ptheta;
     rdotsq = dv<LEAN>(rdotsq * delta, rhosq);
@@ -286,6 +293,42 @@ template <typename T, bool RK45_ASSOC>
 KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
 {
     return k1_impl<T, RK45_ASSOC, LeanDefault<T>::value>(s, a, rhosq_o, sin2theta_o);
+}
+
+// RK45: the k1 of a step that follows an ACCEPTED trial is taken at the point that trial's last stage (k7) was evaluated at, and most
+// of it is the same arithmetic on the same operands: sin^2, rho^2, Delta, tdot, thetadot^2 and |thetadot| come out bit for bit as k7
+// had them (momentum_impl above and k1_impl evaluate identical expressions; the reference recomputes them, :1370-1398).  What differs
+// is phidot -- the RK45 bodies associate its denominator as (sin^2 rho^2) Delta, kerr.h as sin^2 (rho^2 Delta) -- and rdot^2, which
+// depends on it; those, the turning-point logic and the signs are done here as k1_impl does them.  ~70-115 of a trial step's ~1400
+// instructions, on every accepted step; exact.  (Strict arithmetic, double precision.)
+template <typename T, bool LEAN>
+KR_DEV bool k1_from_last_stage(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
+{
+    const T r = s.r, k = s.k, h = s.h;
+    const T sin2theta = s.f_sin2theta, rhosq = s.f_rhosq, delta = s.f_delta;
+    s.pt = s.f_pt;
+    s.pphi = dv<LEAN>(2 * a * r * sin2theta * k + (rhosq - 2 * r) * h, sin2theta * rhosq * delta);
+    const T thetadotsq = s.f_thetadotsq;
+    if (thetadotsq < 0 && s.theta_was_positive) {
+        s.thetadot_sign = -s.thetadot_sign;
+        s.theta_was_positive = false;
+        return true;
+    }
+    if (thetadotsq >= 0) s.theta_was_positive = true;
+    s.ptheta = s.f_abs_ptheta * s.thetadot_sign;
+    T rdotsq = k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta;
+    rdotsq = dv<LEAN>(rdotsq * delta, rhosq);
+    if (rdotsq <= 0 && s.r_was_positive) {
+        s.rdot_sign = -s.rdot_sign;
+        s.r_was_positive = false;
+        s.rdot_flips++;
+    } else if (rdotsq > 0) {
+        s.r_was_positive = true;
+    }
+    s.pr = sq<LEAN>(kr_abs(rdotsq)) * s.rdot_sign;
+    rhosq_o = rhosq;
+    sin2theta_o = sin2theta;
+    return false;
 }
 
 // ==== fast-arithmetic path (kr_params.flags & KR_FLAG_FAST_MATH, double only) =====================================
@@ -761,6 +804,7 @@ KR_DEV int creep_step(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
         todo = 1 + ((long long) c.steplim - s.steps);        // neither flag can change any more: this step and all the remaining ones
         s.steps = c.steplim;
     }
+    s.fsal_valid = false;                                    // theta moves without a last stage having been evaluated there
     const long long bits = (long long) __builtin_bit_cast(unsigned long long, (double) s.theta) + (long long) s.creep_m * todo;
     s.theta = (T) __builtin_bit_cast(double, (unsigned long long) bits);
     s.t = s.t + (T) todo * s.creep_dt;
@@ -819,7 +863,15 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
             }
         } else {
         T rhosq, sin2theta;
-        if (k1_with_flips<T, true>(s, a, rhosq, sin2theta)) return !(s.steps < c.steplim);
+        bool flipped;
+        if constexpr (sizeof(T) == 8) {
+            // wave-uniform: every lane's data from its last accepted stage is valid (else all recompute -- same bits either way)
+            if (__builtin_amdgcn_ballot_w64(!s.fsal_valid) == 0) flipped = k1_from_last_stage<T, LeanDefault<T>::value>(s, a, rhosq, sin2theta);
+            else flipped = k1_with_flips<T, true>(s, a, rhosq, sin2theta);
+        } else {
+            flipped = k1_with_flips<T, true>(s, a, rhosq, sin2theta);
+        }
+        if (flipped) return !(s.steps < c.steplim);
         // flags (:1403-1410): same rhosq / sin2theta values as k1's
         if (s.pt <= 0) s.status |= KR_STATUS_ERGO;
         if ((1 - 2 * s.r / rhosq) * s.pt + (2 * a * s.r * sin2theta / rhosq) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
@@ -898,7 +950,11 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     reflect_poles(theta_new, phi_new, s.thetadot_sign);
 
     T pt7, pr7, ptheta7, pphi7;
-    eval<T, FAST>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
+    Lane<T> last;                   // (only its f_* members are written, and only on the strict double path)
+    if constexpr (!FAST && sizeof(T) == 8)
+        momentum_impl<T, LeanDefault<T>::value>(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a, &last);
+    else
+        eval<T, FAST>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
 
     // error norm over (r, theta) and the step controller (:1508-1519)
     const T err_r = h_try * (D::e1 * pr1 + D::e3 * pr3 + D::e4 * pr4 + D::e5 * pr5 + D::e6 * pr6 + D::e7 * pr7);
@@ -907,8 +963,16 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     const T sc_theta = c.tol * (T(1) + std_max(kr_abs(theta), kr_abs(theta_new)));
     const T err_norm = kr_sqrt(T(0.5) * ((err_r / sc_r) * (err_r / sc_r) + (err_theta / sc_theta) * (err_theta / sc_theta)));
 
-    T fac = T(0.9) * fifth_root_for_controller(T(1) / std_max(err_norm, T(1e-10)));
-    fac = std_max(T(0.1), std_min(T(5.0), fac));
+    // 0.9 (1 / max(err, 1e-10))^0.2 clamped to [0.1, 5] (:1517-1518) IS 5 whenever err <= 1.889e-4 (0.9 x^0.2 >= 5 from x = 5292 on); a ray
+    // whose step is set by a cap rather than by its error -- the polar-axis ray's 100 000 steps -- is there at every step, and the
+    // root costs ~40 instructions.  err <= 1.8e-4 leaves a 1 % margin for the root's rounding; the choice is a pure function of err.
+    const bool saturated = err_norm <= T(1.8e-4);
+    T fac = T(5.0);
+    if (__builtin_amdgcn_ballot_w64(!saturated) != 0) {
+        T f = T(0.9) * fifth_root_for_controller(T(1) / std_max(err_norm, T(1e-10)));
+        f = std_max(T(0.1), std_min(T(5.0), f));
+        fac = saturated ? T(5.0) : f;
+    }
     const T step_new = h_try * fac;
 
     bool commit = false;
@@ -934,6 +998,11 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     s.in_retry = false;
     s.t = t_new; s.r = r_new; s.theta = theta_new; s.phi = phi_new;
     s.pt = pt7; s.pr = pr7; s.ptheta = ptheta7; s.pphi = pphi7;
+    if constexpr (!FAST && sizeof(T) == 8) {
+        s.f_sin2theta = last.f_sin2theta; s.f_rhosq = last.f_rhosq; s.f_delta = last.f_delta; s.f_pt = last.f_pt;
+        s.f_thetadotsq = last.f_thetadotsq; s.f_abs_ptheta = last.f_abs_ptheta;
+        s.fsal_valid = true;
+    }
 
     // Fixed point.  A ray captured by the hole ends up with r - r_horizon ~ 1e-14: the outer cap makes the
     // step so small that r and theta no longer change in fp64, the ray never reaches r <= horizon, and the

@@ -200,6 +200,7 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
                         s.creep_m = 0;
                         s.creep_run = 0;
                         s.creep_mode = false;
+                        s.fsal_valid = false;
                         if (METHOD == KR_RK45) rk45_seed(s, c);
                         if (!loop_cond<T, USE_DEST>(s, c)) {
                             // zero-iteration call: only the epilogue runs
