@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 7
+#define KR_ABI_VERSION 8
 
 /* error codes */
 #define KR_OK          0
@@ -264,6 +264,18 @@ int kr_range_phi_dev_f64(double lo, double hi, void* d_rays, int64_t n, void* st
 /* Raytracer<T>::calculate_momentum()  raytracer.cpp:704-753 */
 int kr_calculate_momentum_f64(double spin, kr_ray_f64* rays, int64_t n);
 int kr_calculate_momentum_dev_f64(double spin, void* d_rays, int64_t n, void* stream);
+/* The same five passes for Raytracer<float>: kr_ray_f32 records, float arithmetic throughout (the reference's float instantiation of the
+ * same source lines; spin, V, lo, hi are float values carried in doubles).  Host-pointer forms copy the whole 84-byte record back. */
+int kr_redshift_start_f32(double spin, double V, int reverse, int projradius, kr_ray_f32* rays, int64_t n);
+int kr_redshift_start_dev_f32(double spin, double V, int reverse, int projradius, void* d_rays, int64_t n, void* stream);
+int kr_redshift_f32(double spin, double V, int reverse, int projradius, int motion, kr_ray_f32* rays, int64_t n);
+int kr_redshift_dev_f32(double spin, double V, int reverse, int projradius, int motion, void* d_rays, int64_t n, void* stream);
+int kr_redshift_dest_f32(double spin, int reverse, kr_ray_f32* rays, int64_t n);
+int kr_redshift_dest_dev_f32(double spin, int reverse, void* d_rays, int64_t n, void* stream);
+int kr_range_phi_f32(double lo, double hi, kr_ray_f32* rays, int64_t n);
+int kr_range_phi_dev_f32(double lo, double hi, void* d_rays, int64_t n, void* stream);
+int kr_calculate_momentum_f32(double spin, kr_ray_f32* rays, int64_t n);
+int kr_calculate_momentum_dev_f32(double spin, void* d_rays, int64_t n, void* stream);
 
 /* ---- ray sources: PointSource / ImagePlane ctors (pointsource.cpp:11-64, imageplane.cpp:11-121) -- */
 int kr_pointsource_init_f64(const kr_pointsource* s, kr_ray_f64* rays, int64_t n);

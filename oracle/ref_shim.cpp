@@ -229,6 +229,35 @@ void ref_redshift_start_f32(void* hv, double V, int reverse, int projradius)
     ((HandleF*) hv)->base->redshift_start((float) V, reverse != 0, projradius != 0);
 }
 
+// the O(N) passes of the float instantiation (raytracer.cpp:420-477, :603-622, :704-753)
+void ref_redshift_f32(void* hv, double V, int reverse, int projradius, int motion)
+{
+    Quiet q;
+    ((HandleF*) hv)->base->redshift((float) V, reverse != 0, projradius != 0, motion);
+}
+
+int ref_redshift_dest_f32(void* hv, int dest_kind, const double* dest_params, int reverse)
+{
+    Quiet q;
+    RayDestination<float>* d = make_dest_f(dest_kind, dest_params);
+    if (!d) return -1;
+    ((HandleF*) hv)->base->redshift(d, reverse != 0);
+    delete d;
+    return 0;
+}
+
+void ref_range_phi_f32(void* hv, double lo, double hi)
+{
+    Quiet q;
+    ((HandleF*) hv)->base->range_phi((float) lo, (float) hi);
+}
+
+void ref_calculate_momentum_f32(void* hv)
+{
+    Quiet q;
+    ((HandleF*) hv)->base->calculate_momentum();
+}
+
 void ref_run_thetalim_f32(void* hv, int method, double theta_max, double r_max, int steplim)
 {
     Quiet q;

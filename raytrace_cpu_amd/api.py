@@ -92,33 +92,35 @@ def trace_release(ticket):
     capi.check(lib(), lib().kr_trace_release(ticket), "kr_trace_release")
 
 
+def _pass(name, rays):
+    """The f64 or f32 entry point of an O(N) pass, by the dtype of `rays`."""
+    f32 = isinstance(rays, np.ndarray) and rays.dtype == capi.RAY_F32
+    _rays_arg(rays, capi.RAY_F32 if f32 else capi.RAY_F64)
+    return getattr(lib(), f"{name}_{'f32' if f32 else 'f64'}")
+
+
 def redshift_start(spin, V, reverse, projradius, rays):
-    _rays_arg(rays, capi.RAY_F64)
-    capi.check(lib(), lib().kr_redshift_start_f64(spin, V, int(reverse), int(projradius), _ptr(rays), len(rays)), "kr_redshift_start")
+    capi.check(lib(), _pass("kr_redshift_start", rays)(spin, V, int(reverse), int(projradius), _ptr(rays), len(rays)), "kr_redshift_start")
     return rays
 
 
 def redshift(spin, V, reverse, projradius, rays, motion=0):
-    _rays_arg(rays, capi.RAY_F64)
-    capi.check(lib(), lib().kr_redshift_f64(spin, V, int(reverse), int(projradius), motion, _ptr(rays), len(rays)), "kr_redshift")
+    capi.check(lib(), _pass("kr_redshift", rays)(spin, V, int(reverse), int(projradius), motion, _ptr(rays), len(rays)), "kr_redshift")
     return rays
 
 
 def redshift_dest(spin, reverse, rays):
-    _rays_arg(rays, capi.RAY_F64)
-    capi.check(lib(), lib().kr_redshift_dest_f64(spin, int(reverse), _ptr(rays), len(rays)), "kr_redshift_dest")
+    capi.check(lib(), _pass("kr_redshift_dest", rays)(spin, int(reverse), _ptr(rays), len(rays)), "kr_redshift_dest")
     return rays
 
 
 def range_phi(rays, lo=-np.pi, hi=np.pi):
-    _rays_arg(rays, capi.RAY_F64)
-    capi.check(lib(), lib().kr_range_phi_f64(lo, hi, _ptr(rays), len(rays)), "kr_range_phi")
+    capi.check(lib(), _pass("kr_range_phi", rays)(lo, hi, _ptr(rays), len(rays)), "kr_range_phi")
     return rays
 
 
 def calculate_momentum(spin, rays):
-    _rays_arg(rays, capi.RAY_F64)
-    capi.check(lib(), lib().kr_calculate_momentum_f64(spin, _ptr(rays), len(rays)), "kr_calculate_momentum")
+    capi.check(lib(), _pass("kr_calculate_momentum", rays)(spin, _ptr(rays), len(rays)), "kr_calculate_momentum")
     return rays
 
 

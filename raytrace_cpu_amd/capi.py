@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -131,6 +131,16 @@ PROTOTYPES = {
     "kr_range_phi_dev_f64": (_int, [_dbl, _dbl, _vp, _i64, _vp]),
     "kr_calculate_momentum_f64": (_int, [_dbl, _vp, _i64]),
     "kr_calculate_momentum_dev_f64": (_int, [_dbl, _vp, _i64, _vp]),
+    "kr_redshift_start_f32": (_int, [_dbl, _dbl, _int, _int, _vp, _i64]),
+    "kr_redshift_start_dev_f32": (_int, [_dbl, _dbl, _int, _int, _vp, _i64, _vp]),
+    "kr_redshift_f32": (_int, [_dbl, _dbl, _int, _int, _int, _vp, _i64]),
+    "kr_redshift_dev_f32": (_int, [_dbl, _dbl, _int, _int, _int, _vp, _i64, _vp]),
+    "kr_redshift_dest_f32": (_int, [_dbl, _int, _vp, _i64]),
+    "kr_redshift_dest_dev_f32": (_int, [_dbl, _int, _vp, _i64, _vp]),
+    "kr_range_phi_f32": (_int, [_dbl, _dbl, _vp, _i64]),
+    "kr_range_phi_dev_f32": (_int, [_dbl, _dbl, _vp, _i64, _vp]),
+    "kr_calculate_momentum_f32": (_int, [_dbl, _vp, _i64]),
+    "kr_calculate_momentum_dev_f32": (_int, [_dbl, _vp, _i64, _vp]),
     "kr_pointsource_init_f64": (_int, [P(PointSourceSpec), _vp, _i64]),
     "kr_pointsource_init_dev_f64": (_int, [P(PointSourceSpec), _vp, _i64, _vp]),
     "kr_imageplane_init_f64": (_int, [P(ImagePlaneSpec), _vp, _i64]),

@@ -22,11 +22,11 @@
 namespace kr {
 
 // implemented in kr_post.hip
-int redshift_start_dev(double spin, double V, int reverse, int projradius, void* d, int64_t n, hipStream_t st);
-int redshift_dev(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, hipStream_t st);
-int redshift_dest_dev(double spin, int reverse, void* d, int64_t n, hipStream_t st);
-int range_phi_dev(double lo, double hi, void* d, int64_t n, hipStream_t st);
-int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st);
+int redshift_start_dev(double spin, double V, int reverse, int projradius, void* d, int64_t n, hipStream_t st, bool f32 = false);
+int redshift_dev(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, hipStream_t st, bool f32 = false);
+int redshift_dest_dev(double spin, int reverse, void* d, int64_t n, hipStream_t st, bool f32 = false);
+int range_phi_dev(double lo, double hi, void* d, int64_t n, hipStream_t st, bool f32 = false);
+int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st, bool f32 = false);
 int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st);
 int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st);
 int reduce_emissivity_dev(const kr_emis_bins* b, const void* d, int64_t n, void* d_hist, hipStream_t st);
@@ -403,6 +403,59 @@ int kr_calculate_momentum_f64(double spin, kr_ray_f64* rays, int64_t n)
 {
     return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, nullptr,
                             [&](void* d) { return calculate_momentum_dev(spin, d, n, nullptr); }, WriteBack{offsetof(kr_ray_f64, pt), 4});
+}
+
+// The same passes for Raytracer<float> (kr_ray_f32 records, float arithmetic; the scalars are float values carried in doubles).
+// Host-pointer forms copy the whole 84-byte record back.
+int kr_redshift_start_dev_f32(double spin, double V, int reverse, int projradius, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : redshift_start_dev(spin, V, reverse, projradius, d, n, (hipStream_t) st, true);
+}
+int kr_redshift_start_f32(double spin, double V, int reverse, int projradius, kr_ray_f32* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f32), true, true, nullptr,
+                            [&](void* d) { return redshift_start_dev(spin, V, reverse, projradius, d, n, nullptr, true); });
+}
+int kr_redshift_dev_f32(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : redshift_dev(spin, V, reverse, projradius, motion, d, n, (hipStream_t) st, true);
+}
+int kr_redshift_f32(double spin, double V, int reverse, int projradius, int motion, kr_ray_f32* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f32), true, true, nullptr,
+                            [&](void* d) { return redshift_dev(spin, V, reverse, projradius, motion, d, n, nullptr, true); });
+}
+int kr_redshift_dest_dev_f32(double spin, int reverse, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : redshift_dest_dev(spin, reverse, d, n, (hipStream_t) st, true);
+}
+int kr_redshift_dest_f32(double spin, int reverse, kr_ray_f32* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f32), true, true, nullptr,
+                            [&](void* d) { return redshift_dest_dev(spin, reverse, d, n, nullptr, true); });
+}
+int kr_range_phi_dev_f32(double lo, double hi, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : range_phi_dev(lo, hi, d, n, (hipStream_t) st, true);
+}
+int kr_range_phi_f32(double lo, double hi, kr_ray_f32* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f32), true, true, nullptr,
+                            [&](void* d) { return range_phi_dev(lo, hi, d, n, nullptr, true); });
+}
+int kr_calculate_momentum_dev_f32(double spin, void* d, int64_t n, void* st)
+{
+    int rc = require_device();
+    return rc != KR_OK ? rc : calculate_momentum_dev(spin, d, n, (hipStream_t) st, true);
+}
+int kr_calculate_momentum_f32(double spin, kr_ray_f32* rays, int64_t n)
+{
+    return with_staged_rays(rays, n, sizeof(kr_ray_f32), true, true, nullptr,
+                            [&](void* d) { return calculate_momentum_dev(spin, d, n, nullptr, true); });
 }
 
 // ---- sources -----------------------------------------------------------------------------------------------

@@ -31,16 +31,24 @@ inline int grid_for(int64_t n, int cap_blocks = 256 * 16)
 }
 
 // Kerr metric in the (e2nu, e2psi, omega) form used throughout the reference
-// (raytracer.cpp:370-388, :491-509, :564-582, :632-639)
+// (raytracer.cpp:370-388, :491-509, :564-582, :632-639).  Everything up to calculate_momentum below is a template over
+// the ray record R (kr_ray_f64 / kr_ray_f32) and computes in the record's scalar type, like the reference's
+// Raytracer<double> / Raytracer<float> instantiations of the same source lines.
+template <typename T>
 struct Metric {
-    double rhosq, delta, sigmasq, e2nu, e2psi, omega;
-    double g00, g03, g11, g22, g33;
+    T rhosq, delta, sigmasq, e2nu, e2psi, omega;
+    T g00, g03, g11, g22, g33;
 };
 
-KR_DEV Metric kerr_metric(double r, double theta, double a)
+template <typename R> struct ScalarOf;
+template <> struct ScalarOf<kr_ray_f64> { using type = double; };
+template <> struct ScalarOf<kr_ray_f32> { using type = float; };
+
+template <typename T>
+KR_DEV Metric<T> kerr_metric(T r, T theta, T a)
 {
-    Metric m;
-    const double st = kr_sin(theta), ct = kr_cos(theta);
+    Metric<T> m;
+    const T st = kr_sin(theta), ct = kr_cos(theta);
     m.rhosq = r * r + (a * ct) * (a * ct);
     m.delta = r * r - 2 * r + a * a;
     m.sigmasq = (r * r + a * a) * (r * r + a * a) - a * a * m.delta * st * st;
@@ -57,10 +65,11 @@ KR_DEV Metric kerr_metric(double r, double theta, double a)
 
 // sum_ij g[i][j] * et[i] * p[j] over all 16 entries in row-major order, zeros included, exactly like the
 // reference loops (raytracer.cpp:412-415, :547-550): a 0 * inf or 0 * NaN term must poison the sum the same way.
-KR_DEV double energy_dot(const Metric& m, const double* et, const double* p)
+template <typename T>
+KR_DEV T energy_dot(const Metric<T>& m, const T* et, const T* p)
 {
-    const double g[16] = {m.g00, 0, 0, m.g03, 0, m.g11, 0, 0, 0, 0, m.g22, 0, m.g03, 0, 0, m.g33};
-    double e = 0;
+    const T g[16] = {m.g00, 0, 0, m.g03, 0, m.g11, 0, 0, 0, 0, m.g22, 0, m.g03, 0, 0, m.g33};
+    T e = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -68,7 +77,8 @@ KR_DEV double energy_dot(const Metric& m, const double* et, const double* p)
     return e;
 }
 
-KR_DEV double keplerian_V(double a, double r, double theta, bool projradius)
+template <typename T>
+KR_DEV T keplerian_V(T a, T r, T theta, bool projradius)
 {
     if (projradius) return 1 / (a + r * kr_sin(theta) * kr_sqrt(r * kr_sin(theta)));
     return 1 / (a + r * kr_sqrt(r));
@@ -77,61 +87,65 @@ KR_DEV double keplerian_V(double a, double r, double theta, bool projradius)
 // ---- redshift_start (raytracer.cpp:342-417) ------------------------------------------------------------
 // V is a by-value parameter that the reference's loop overwrites when it equals -1, so the orbital velocity
 // computed at the FIRST record (index 0, valid or not) is used for every ray.
-KR_DEV double emit_value(const kr_ray_f64& ray, double spin, double a, double V, int reverse)
+template <typename R, typename T = typename ScalarOf<R>::type>
+KR_DEV T emit_value(const R& ray, T spin, T a, T V, int reverse)
 {
-    const double r = ray.r, theta = ray.theta;
-    const Metric m = kerr_metric(r, theta, a);
-    const double et[4] = {(1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu), 0, 0,
-                          (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu)};
-    double p[4];
-    momentum<double>(p[0], p[1], p[2], p[3], ray.k, ray.h, ray.Q, ray.rdot_sign, ray.thetadot_sign, r, theta, spin);
+    const T r = ray.r, theta = ray.theta;
+    const Metric<T> m = kerr_metric<T>(r, theta, a);
+    const T et[4] = {(1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu), 0, 0,
+                     (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu)};
+    T p[4];
+    momentum<T>(p[0], p[1], p[2], p[3], ray.k, ray.h, ray.Q, ray.rdot_sign, ray.thetadot_sign, r, theta, spin);
     if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
-    return energy_dot(m, et, p);
+    return energy_dot<T>(m, et, p);
 }
 
+template <typename R, typename T = typename ScalarOf<R>::type>
 __global__ void __launch_bounds__(kBlock)
-redshift_start_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double V, int reverse, int projradius)
+redshift_start_kernel(R* __restrict__ rays, long long n, T spin, T V, int reverse, int projradius)
 {
-    const double a = reverse ? -1 * spin : spin;
-    if (V == -1) V = keplerian_V(a, rays[0].r, rays[0].theta, projradius != 0);
+    const T a = reverse ? -1 * spin : spin;
+    if (V == -1) V = keplerian_V<T>(a, rays[0].r, rays[0].theta, projradius != 0);
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
-        kr_ray_f64* ray = &rays[i];
-        kr_ray_f64 v;
+        R* ray = &rays[i];
+        R v;
         v.r = ray->r; v.theta = ray->theta; v.k = ray->k; v.h = ray->h; v.Q = ray->Q; v.rdot_sign = ray->rdot_sign; v.thetadot_sign = ray->thetadot_sign;
         ray->emit = emit_value(v, spin, a, V, reverse);
     }
 }
 
 // ---- redshift(V, ...) (raytracer.cpp:420-447, :480-553) ----------------------------------------------
-KR_DEV double redshift_value(const kr_ray_f64& ray, double spin, double V_in, int reverse, int projradius, int motion)
+template <typename R, typename T = typename ScalarOf<R>::type>
+KR_DEV T redshift_value(const R& ray, T spin, T V_in, int reverse, int projradius, int motion)
 {
-    const double a = reverse ? -1 * spin : spin;
-    const double r = ray.r, theta = ray.theta;
-    const Metric m = kerr_metric(r, theta, a);
-    double V = V_in;
-    double et[4] = {0, 0, 0, 0};
+    const T a = reverse ? -1 * spin : spin;
+    const T r = ray.r, theta = ray.theta;
+    const Metric<T> m = kerr_metric<T>(r, theta, a);
+    T V = V_in;
+    T et[4] = {0, 0, 0, 0};
     if (motion == 0) {
-        if (V == -1) V = keplerian_V(a, r, theta, projradius != 0);
+        if (V == -1) V = keplerian_V<T>(a, r, theta, projradius != 0);
         et[0] = (1 / kr_sqrt(m.e2nu)) / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
         et[3] = (1 / kr_sqrt(m.e2nu)) * V / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
     } else if (motion == 1) {
         if (V < 0) V = kr_abs(V) * (r * r - 2 * r + spin + spin) / (r * r + spin * spin);   // sic, :531
-        et[0] = 1. / kr_sqrt(m.g00 + m.g11 * V * V);
+        et[0] = (T) (1. / kr_sqrt(m.g00 + m.g11 * V * V));                                  // (a double division in the float build too, :533)
         et[1] = V * et[0];
     }
-    double p[4];
-    momentum<double>(p[0], p[1], p[2], p[3], ray.k, ray.h, ray.Q, ray.rdot_sign, ray.thetadot_sign, r, theta, spin);
+    T p[4];
+    momentum<T>(p[0], p[1], p[2], p[3], ray.k, ray.h, ray.Q, ray.rdot_sign, ray.thetadot_sign, r, theta, spin);
     if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
-    const double recv = energy_dot(m, et, p);
+    const T recv = energy_dot<T>(m, et, p);
     return reverse ? recv / ray.emit : ray.emit / recv;
 }
 
+template <typename R, typename T = typename ScalarOf<R>::type>
 __global__ void __launch_bounds__(kBlock)
-redshift_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double V_in, int reverse, int projradius, int motion)
+redshift_kernel(R* __restrict__ rays, long long n, T spin, T V_in, int reverse, int projradius, int motion)
 {
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
-        kr_ray_f64* ray = &rays[i];
-        kr_ray_f64 v;
+        R* ray = &rays[i];
+        R v;
         v.r = ray->r; v.theta = ray->theta; v.k = ray->k; v.h = ray->h; v.Q = ray->Q; v.rdot_sign = ray->rdot_sign; v.thetadot_sign = ray->thetadot_sign;
         v.emit = ray->emit;
         ray->redshift = redshift_value(v, spin, V_in, reverse, projradius, motion);
@@ -140,26 +154,29 @@ redshift_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, double 
 
 // ---- redshift(RayDestination*, ...) with the default four_velocity (raytracer.cpp:450-477, :556-600;
 //      ray_destination.h:59-78) -----------------------------------------------------------------------
+template <typename R, typename T = typename ScalarOf<R>::type>
 __global__ void __launch_bounds__(kBlock)
-redshift_dest_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, int reverse)
+redshift_dest_kernel(R* __restrict__ rays, long long n, T spin, int reverse)
 {
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
-        kr_ray_f64* ray = &rays[i];
-        const double r = ray->r, theta = ray->theta;
-        const Metric m = kerr_metric(r, theta, spin);
-        const double V = 1 / (spin + r * kr_sqrt(r));
-        const double gamma_factor = 1 / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
-        const double et[4] = {gamma_factor / kr_sqrt(m.e2nu), 0, 0, gamma_factor * V / kr_sqrt(m.e2nu)};
-        double p[4];
-        momentum<double>(p[0], p[1], p[2], p[3], ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, r, theta, spin);
+        R* ray = &rays[i];
+        const T r = ray->r, theta = ray->theta;
+        const Metric<T> m = kerr_metric<T>(r, theta, spin);
+        const T V = 1 / (spin + r * kr_sqrt(r));
+        const T gamma_factor = 1 / kr_sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
+        const T et[4] = {gamma_factor / kr_sqrt(m.e2nu), 0, 0, gamma_factor * V / kr_sqrt(m.e2nu)};
+        T p[4];
+        momentum<T>(p[0], p[1], p[2], p[3], ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, r, theta, spin);
         if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
-        const double recv = energy_dot(m, et, p);
+        const T recv = energy_dot<T>(m, et, p);
         ray->redshift = reverse ? recv / ray->emit : ray->emit / recv;
     }
 }
 
-// ---- range_phi (raytracer.cpp:603-622): repeated +-2pi like the reference, so the result is bit-identical ----
-KR_DEV double range_phi_value(double phi, int steps, double lo, double hi)
+// ---- range_phi (raytracer.cpp:603-622): repeated +-2pi like the reference, so the result is bit-identical.  2 * M_PI is a double:
+//      in the float build each `phi -= 2 * M_PI` is a double subtraction rounded back to float, here as there. ----
+template <typename T>
+KR_DEV T range_phi_value(T phi, int steps, T lo, T hi)
 {
     if (kr_abs(phi) > 1000 || phi != phi || !(steps > 0)) return phi;
     while (phi >= hi) phi -= 2 * kPi;
@@ -167,22 +184,24 @@ KR_DEV double range_phi_value(double phi, int steps, double lo, double hi)
     return phi;
 }
 
-__global__ void __launch_bounds__(kBlock) range_phi_kernel(kr_ray_f64* __restrict__ rays, long long n, double lo, double hi)
+template <typename R, typename T = typename ScalarOf<R>::type>
+__global__ void __launch_bounds__(kBlock) range_phi_kernel(R* __restrict__ rays, long long n, T lo, T hi)
 {
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
-        const double phi = rays[i].phi;
-        const double wrapped = range_phi_value(phi, rays[i].steps, lo, hi);
+        const T phi = rays[i].phi;
+        const T wrapped = range_phi_value<T>(phi, rays[i].steps, lo, hi);
         if (!(wrapped == phi) && wrapped == wrapped) rays[i].phi = wrapped;
     }
 }
 
 // ---- calculate_momentum (raytracer.cpp:704-753) ---------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) calculate_momentum_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin)
+template <typename R, typename T = typename ScalarOf<R>::type>
+__global__ void __launch_bounds__(kBlock) calculate_momentum_kernel(R* __restrict__ rays, long long n, T spin)
 {
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
-        kr_ray_f64* ray = &rays[i];
-        double pt, pr, ptheta, pphi;
-        momentum<double>(pt, pr, ptheta, pphi, ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, ray->r, ray->theta, spin);
+        R* ray = &rays[i];
+        T pt, pr, ptheta, pphi;
+        momentum<T>(pt, pr, ptheta, pphi, ray->k, ray->h, ray->Q, ray->rdot_sign, ray->thetadot_sign, ray->r, ray->theta, spin);
         ray->pt = pt; ray->pr = pr; ray->ptheta = ptheta; ray->pphi = pphi;
     }
 }
@@ -264,7 +283,7 @@ pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_poin
         // the reference's loop overwrites V with the orbital velocity at rays[0] of the WHOLE source and keeps it for every ray
         // (raytracer.cpp:389-393): source ray 0, not this shard's first ray
         const kr_ray_f64 r0 = pointsource_ray(s, n_grid, n_beta, 0);
-        V = keplerian_V(a, r0.r, r0.theta, projradius != 0);
+        V = keplerian_V<double>(a, r0.r, r0.theta, projradius != 0);
     }
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
         kr_ray_f64 ray = pointsource_ray(s, n_grid, n_beta, first + slot * stride);
@@ -350,7 +369,7 @@ imageplane_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_image
     const double am = reverse ? -1 * spin : spin;
     if (V == -1) {
         const kr_ray_f64 r0 = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, 0);      // source ray 0 (raytracer.cpp:389-393), not the shard's first
-        V = keplerian_V(am, r0.r, r0.theta, projradius != 0);
+        V = keplerian_V<double>(am, r0.r, r0.theta, projradius != 0);
     }
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
         // slot -> source ray: runs of `run` consecutive rays, `stride` apart (run = 1: plain ray-cyclic)
@@ -434,7 +453,7 @@ post_emissivity_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, 
         v.emit = ray->emit;
         const int steps = ray->steps;
         const double phi = ray->phi;
-        const double wrapped = range_phi_value(phi, steps, lo, hi);
+        const double wrapped = range_phi_value<double>(phi, steps, lo, hi);
         if (!(wrapped == phi) && wrapped == wrapped) ray->phi = wrapped;
         const double g = redshift_value(v, spin, V, reverse, projradius, motion);
         ray->redshift = g;
@@ -509,7 +528,7 @@ post_image_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, doubl
         const double g = redshift_value(v, spin, V, reverse, projradius, motion);
         ray->redshift = g;
         const double phi = ray->phi;
-        const double wrapped = range_phi_value(phi, steps, lo, hi);
+        const double wrapped = range_phi_value<double>(phi, steps, lo, hi);
         if (!(wrapped == phi) && wrapped == wrapped) ray->phi = wrapped;
         hits += image_accumulate(planes, npix, b, steps, v.r, v.theta, wrapped, ray->t, g, ray->alpha, ray->beta);
     }
@@ -595,44 +614,39 @@ int arith_probe_dev(int op, const double* a, const double* b, double* out, int64
     return KR_OK;
 }
 
-int redshift_start_dev(double spin, double V, int reverse, int projradius, void* d, int64_t n, hipStream_t st)
+// f32 != 0: the records are kr_ray_f32 and the pass computes in float (the scalars are float values carried in doubles)
+#define KR_POST_LAUNCH(kernel, ...)                                                                                      \
+    do {                                                                                                                 \
+        if (n <= 0) return KR_OK;                                                                                        \
+        if (f32) hipLaunchKernelGGL((kernel<kr_ray_f32, float>), dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f32*) d, (long long) n, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kernel<kr_ray_f64, double>), dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, __VA_ARGS__);   \
+        KR_LAUNCH_CHECK();                                                                                               \
+        return KR_OK;                                                                                                    \
+    } while (0)
+
+int redshift_start_dev(double spin, double V, int reverse, int projradius, void* d, int64_t n, hipStream_t st, bool f32)
 {
-    if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(redshift_start_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, V, reverse, projradius);
-    KR_LAUNCH_CHECK();
-    return KR_OK;
+    KR_POST_LAUNCH(redshift_start_kernel, spin, V, reverse, projradius);
 }
 
-int redshift_dev(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, hipStream_t st)
+int redshift_dev(double spin, double V, int reverse, int projradius, int motion, void* d, int64_t n, hipStream_t st, bool f32)
 {
-    if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(redshift_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, V, reverse, projradius, motion);
-    KR_LAUNCH_CHECK();
-    return KR_OK;
+    KR_POST_LAUNCH(redshift_kernel, spin, V, reverse, projradius, motion);
 }
 
-int redshift_dest_dev(double spin, int reverse, void* d, int64_t n, hipStream_t st)
+int redshift_dest_dev(double spin, int reverse, void* d, int64_t n, hipStream_t st, bool f32)
 {
-    if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(redshift_dest_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin, reverse);
-    KR_LAUNCH_CHECK();
-    return KR_OK;
+    KR_POST_LAUNCH(redshift_dest_kernel, spin, reverse);
 }
 
-int range_phi_dev(double lo, double hi, void* d, int64_t n, hipStream_t st)
+int range_phi_dev(double lo, double hi, void* d, int64_t n, hipStream_t st, bool f32)
 {
-    if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(range_phi_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, lo, hi);
-    KR_LAUNCH_CHECK();
-    return KR_OK;
+    KR_POST_LAUNCH(range_phi_kernel, lo, hi);
 }
 
-int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st)
+int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st, bool f32)
 {
-    if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(calculate_momentum_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, spin);
-    KR_LAUNCH_CHECK();
-    return KR_OK;
+    KR_POST_LAUNCH(calculate_momentum_kernel, spin);
 }
 
 int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st)

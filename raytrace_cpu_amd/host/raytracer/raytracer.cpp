@@ -1,11 +1,10 @@
 // raytracer/raytracer.cpp -- Raytracer<T> members of the host-side API mirror.
 //
-// run_raytrace (both overloads; reference raytracer.cpp:63-127, :972-1034) and, for T = double, the O(N)
-// passes (redshift_start :342-417, redshift :420-477, range_phi :603-622, calculate_momentum :704-753) are
-// calls into libkrtrace.so (include/kr_trace.h) and execute on the GPU.  The float instantiation
-// (reference raytracer.cpp:1897) traces on the GPU as well (kr_trace_f32); its O(N) passes, the per-ray
-// ray_redshift() helpers and redshift() with a user-defined velocity field are plain host loops, as they
-// are in the reference, because they call back into virtual / per-ray host code.
+// run_raytrace (both overloads; reference raytracer.cpp:63-127, :972-1034) and the O(N) passes (redshift_start :342-417,
+// redshift :420-477, range_phi :603-622, calculate_momentum :704-753) are calls into libkrtrace.so (include/kr_trace.h)
+// and execute on the GPU, for Raytracer<double> (kr_*_f64) and for the float instantiation (reference raytracer.cpp:1897;
+// kr_*_f32) alike.  Host code is left only where the reference calls back into per-ray virtual functions: the ray_redshift()
+// helpers and redshift() with a user-defined velocity field.
 
 #include "raytracer.h"
 
@@ -320,57 +319,49 @@ T Raytracer<T>::ray_redshift(const T et[4], bool reverse, T r, T theta, T phi, T
     return (reverse) ? recv / emit : emit / recv;
 }
 
-// ---- O(N) passes: GPU for double, host loops for float ---------------------------------------------------------
+// ---- O(N) passes: streaming kernels over rays[] for both instantiations (kr_*_f64 / kr_*_f32) -----------------------
+// Only a user-defined RayDestination::four_velocity() keeps a host loop (a per-ray virtual call, as in the reference).
 namespace {
 
-template <typename T> struct OnDevice { static constexpr bool value = false; };
-template <> struct OnDevice<double> { static constexpr bool value = true; };
+struct PassF64 {
+    using ray = kr_ray_f64;
+    static int redshift_start(double a, double V, int rev, int pr, ray* r, int64_t n) { return kr_redshift_start_f64(a, V, rev, pr, r, n); }
+    static int redshift(double a, double V, int rev, int pr, int motion, ray* r, int64_t n) { return kr_redshift_f64(a, V, rev, pr, motion, r, n); }
+    static int redshift_dest(double a, int rev, ray* r, int64_t n) { return kr_redshift_dest_f64(a, rev, r, n); }
+    static int range_phi(double lo, double hi, ray* r, int64_t n) { return kr_range_phi_f64(lo, hi, r, n); }
+    static int calculate_momentum(double a, ray* r, int64_t n) { return kr_calculate_momentum_f64(a, r, n); }
+};
+struct PassF32 {
+    using ray = kr_ray_f32;
+    static int redshift_start(double a, double V, int rev, int pr, ray* r, int64_t n) { return kr_redshift_start_f32(a, V, rev, pr, r, n); }
+    static int redshift(double a, double V, int rev, int pr, int motion, ray* r, int64_t n) { return kr_redshift_f32(a, V, rev, pr, motion, r, n); }
+    static int redshift_dest(double a, int rev, ray* r, int64_t n) { return kr_redshift_dest_f32(a, rev, r, n); }
+    static int range_phi(double lo, double hi, ray* r, int64_t n) { return kr_range_phi_f32(lo, hi, r, n); }
+    static int calculate_momentum(double a, ray* r, int64_t n) { return kr_calculate_momentum_f32(a, r, n); }
+};
+template <typename T> struct PassOf;
+template <> struct PassOf<double> { using type = PassF64; };
+template <> struct PassOf<float> { using type = PassF32; };
 
-inline kr_ray_f64* as_kr(Ray<double>* r) { return reinterpret_cast<kr_ray_f64*>(r); }
-inline kr_ray_f64* as_kr(Ray<float>*) { return nullptr; }
+template <typename T>
+inline typename PassOf<T>::type::ray* as_kr(Ray<T>* r) { return reinterpret_cast<typename PassOf<T>::type::ray*>(r); }
 
 }  // namespace
 
 template <typename T>
 void Raytracer<T>::redshift_start(T V, bool reverse, bool projradius)
 {
-    if (OnDevice<T>::value) {
-        mark("redshift_start: begin");
-        check(kr_redshift_start_f64(spin, V, reverse, projradius, as_kr(rays), nRays), "kr_redshift_start");
-        mark("redshift_start: end");
-        return;
-    }
-    // host loop; V carries over from ray to ray once replaced, exactly like the reference's by-value parameter
-    for (int ray = 0; ray < nRays; ray++) {
-        Ray<T>& R = rays[ray];
-        const T a = (reverse) ? -1 * spin : spin;
-        const HostMetric<T> gm(R.r, R.theta, a);
-        if (V == -1 && projradius)
-            V = 1 / (a + R.r * sin(R.theta) * sqrt(R.r * sin(R.theta)));
-        else if (V == -1)
-            V = 1 / (a + R.r * sqrt(R.r));
-        const T et[] = {(1 / sqrt(gm.m.e2nu)) / sqrt(1 - (V - gm.m.omega) * (V - gm.m.omega) * gm.m.e2psi / gm.m.e2nu), 0, 0,
-                        (1 / sqrt(gm.m.e2nu)) * V / sqrt(1 - (V - gm.m.omega) * (V - gm.m.omega) * gm.m.e2psi / gm.m.e2nu)};
-        T p[4];
-        momentum_from_consts<T>(p[0], p[1], p[2], p[3], R.k, R.h, R.Q, R.rdot_sign, R.thetadot_sign, R.r, R.theta, R.phi, spin);
-        if (reverse) { p[1] *= -1; p[2] *= -1; p[3] *= -1; }
-        R.emit = gm.contract(et, p);
-    }
+    mark("redshift_start: begin");
+    check(PassOf<T>::type::redshift_start(spin, V, reverse, projradius, as_kr<T>(rays), nRays), "kr_redshift_start");
+    mark("redshift_start: end");
 }
 
 template <typename T>
 void Raytracer<T>::redshift(T V, bool reverse, bool projradius, int motion)
 {
-    if (OnDevice<T>::value) {
-        mark("redshift: begin");
-        check(kr_redshift_f64(spin, V, reverse, projradius, motion, as_kr(rays), nRays), "kr_redshift");
-        mark("redshift: end");
-        return;
-    }
-    for (int ray = 0; ray < nRays; ray++) {
-        Ray<T>& R = rays[ray];
-        R.redshift = ray_redshift(V, reverse, projradius, R.r, R.theta, R.phi, R.k, R.h, R.Q, R.rdot_sign, R.thetadot_sign, R.emit, motion);
-    }
+    mark("redshift: begin");
+    check(PassOf<T>::type::redshift(spin, V, reverse, projradius, motion, as_kr<T>(rays), nRays), "kr_redshift");
+    mark("redshift: end");
 }
 
 template <typename T>
@@ -380,8 +371,8 @@ void Raytracer<T>::redshift(RayDestination<T>* dest, bool reverse, bool projradi
     int kind = 0;
     double sp[4];
     bool default_velocity = false;
-    if (OnDevice<T>::value && builtin_destination(dest, kind, sp, default_velocity) && default_velocity) {
-        check(kr_redshift_dest_f64(spin, reverse, as_kr(rays), nRays), "kr_redshift_dest");
+    if (builtin_destination(dest, kind, sp, default_velocity) && default_velocity) {
+        check(PassOf<T>::type::redshift_dest(spin, reverse, as_kr<T>(rays), nRays), "kr_redshift_dest");
         return;
     }
     // user-defined velocity field: per-ray virtual call, host loop as in the reference (:467-476)
@@ -396,30 +387,15 @@ void Raytracer<T>::redshift(RayDestination<T>* dest, bool reverse, bool projradi
 template <typename T>
 void Raytracer<T>::range_phi(T min, T max)
 {
-    if (OnDevice<T>::value) {
-        mark("range_phi: begin");
-        check(kr_range_phi_f64(min, max, as_kr(rays), nRays), "kr_range_phi");
-        mark("range_phi: end");
-        return;
-    }
-    for (int ray = 0; ray < nRays; ray++) {
-        if (abs(rays[ray].phi) > 1000 || rays[ray].phi != rays[ray].phi || !(rays[ray].steps > 0)) continue;
-        while (rays[ray].phi >= max) rays[ray].phi -= 2 * M_PI;
-        while (rays[ray].phi < min) rays[ray].phi += 2 * M_PI;
-    }
+    mark("range_phi: begin");
+    check(PassOf<T>::type::range_phi(min, max, as_kr<T>(rays), nRays), "kr_range_phi");
+    mark("range_phi: end");
 }
 
 template <typename T>
 void Raytracer<T>::calculate_momentum()
 {
-    if (OnDevice<T>::value) {
-        check(kr_calculate_momentum_f64(spin, as_kr(rays), nRays), "kr_calculate_momentum");
-        return;
-    }
-    for (int ray = 0; ray < nRays; ray++) {
-        Ray<T>& R = rays[ray];
-        momentum_from_consts<T>(R.pt, R.pr, R.ptheta, R.pphi, R.k, R.h, R.Q, R.rdot_sign, R.thetadot_sign, R.r, R.theta, R.phi, spin);
-    }
+    check(PassOf<T>::type::calculate_momentum(spin, as_kr<T>(rays), nRays), "kr_calculate_momentum");
 }
 
 // ---- constants of motion for the ray sources (host, O(N)); reference raytracer.cpp:625-701 ------------------------

@@ -2,7 +2,10 @@
 """Regenerates tests/golden/f32_*.npz from the compiled reference's FLOAT instantiation (Raytracer<float>,
 reference raytracer.cpp:1897) through oracle/_ref/libkr_ref.so.  Build container only.  There is no float oracle
 restatement: the f32 HIP kernels are pinned directly by these reference outputs.
-  init / final__<run>: 84-B Ray<float> records (fields the reference leaves indeterminate are zeroed)."""
+  init / final__<run>: 84-B Ray<float> records (fields the reference leaves indeterminate are zeroed); init carries `emit`
+  from the float redshift_start.
+  post__<run>: final__<run> after the float range_phi(-pi, pi), redshift(V, reverse, projradius) of the case and
+  calculate_momentum(); postdest__<run> (stop-surface runs): the `redshift` field after redshift(RayDestination*)."""
 import ctypes as C
 import os
 import sys
@@ -29,6 +32,10 @@ def lib():
         "ref_redshift_start_f32": (None, [_vp, _dbl, _int, _int]),
         "ref_run_thetalim_f32": (None, [_vp, _int, _dbl, _dbl, _int]),
         "ref_run_dest_f32": (_int, [_vp, _int, _int, P(_dbl), _dbl, _int]),
+        "ref_redshift_f32": (None, [_vp, _dbl, _int, _int, _int]),
+        "ref_redshift_dest_f32": (_int, [_vp, _int, P(_dbl), _int]),
+        "ref_range_phi_f32": (None, [_vp, _dbl, _dbl]),
+        "ref_calculate_momentum_f32": (None, [_vp]),
     }
     for n, (r, a) in protos.items():
         f = getattr(L, n)
@@ -62,8 +69,17 @@ def run(L, case, params):
     else:
         assert L.ref_run_dest_f32(h, params.integrator, params.stop_kind, (C.c_double * 4)(*params.stop_params), params.r_max, params.steplim) == 0
     final = view.copy()
+    L.ref_range_phi_f32(h, -np.pi, np.pi)
+    V, reverse, projradius = case["post"]
+    L.ref_redshift_f32(h, V, reverse, projradius, 0)
+    L.ref_calculate_momentum_f32(h)
+    post = view.copy()
+    postdest = None
+    if params.stop_kind != capi.STOP_THETA:
+        assert L.ref_redshift_dest_f32(h, params.stop_kind, (C.c_double * 4)(*params.stop_params), reverse) == 0
+        postdest = view["redshift"].copy()
     L.ref_free_f32(h)
-    return init, final
+    return init, final, post, postdest
 
 
 F32_RUNS = {"ps_h10": ("euler", "rk4", "rk45"), "ip15": ("rk4", "rk4_isco")}
@@ -75,11 +91,18 @@ if __name__ == "__main__":
     for name, runs in F32_RUNS.items():
         out = {}
         for r in runs:
-            init, final = run(L, cases[name], capi.copy_params(cases[name]["runs"][r], steplim=F32_STEPLIM))
+            init, final, post, postdest = run(L, cases[name], capi.copy_params(cases[name]["runs"][r], steplim=F32_STEPLIM))
             out["init"] = init
             out[f"final__{r}"] = final
+            out[f"post__{r}"] = post
+            if postdest is not None:
+                out[f"postdest__{r}"] = postdest
             live = final["steps"] != -1
             print(name, r, len(init), "rays; steps sum", int(np.abs(final["steps"][live].astype(np.int64)).sum()), "steplim rays", int((final["steps"] < -1).sum()))
         path = os.path.join(gc.GOLDEN_DIR, f"f32_{name}.npz")
+        if os.path.exists(path):                                  # regenerating must reproduce what is already committed
+            old = np.load(path)
+            for k in old.files:
+                assert old[k].tobytes() == out[k].tobytes(), f"{name}: {k} changed"
         np.savez_compressed(path, **out)
         print(" ->", path, os.path.getsize(path) // 1024, "KiB")

@@ -328,6 +328,60 @@ def test_f32_trace_vs_reference_float(krlib, case_name, run):
     assert abs(s_out - s_want) <= 0.02 * s_want
 
 
+def _f32_rel_err(got, want):
+    a, b = got.astype(np.float64), want.astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        err = np.abs(a - b) / np.maximum(np.abs(b), 1e-30)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    return np.where(same, 0.0, err)
+
+
+@pytest.mark.parametrize("case_name,run", [("ps_h10", "euler"), ("ps_h10", "rk4"), ("ps_h10", "rk45"), ("ip15", "rk4"), ("ip15", "rk4_isco")])
+def test_f32_passes_vs_reference_float(krlib, case_name, run):
+    """The O(N) passes of the float instantiation on the device (kr_redshift_start_f32, kr_range_phi_f32, kr_redshift_f32,
+    kr_redshift_dest_f32, kr_calculate_momentum_f32) against the compiled reference's Raytracer<float>, pass by pass ON THE REFERENCE'S
+    OWN INPUTS (fixtures: tests/golden/make_golden_f32.py), so that each comparison is one evaluation deep: range_phi bit for bit
+    (additions of a double 2 pi rounded to float, no library call); the others bit for bit on >= 99 % of the rays (the device's sinf /
+    cosf may differ from glibc's in the last bit)."""
+    g = np.load(gc.golden_path(f"f32_{case_name}"))
+    case = CASES[case_name]
+    spin = case["runs"][run].spin                 # the Raytracer member (already negated for an ImagePlane)
+    # redshift_start on the source's records
+    init = g["init"].copy()
+    init["emit"] = 0
+    api.redshift_start(spin, *case["start"], init)
+    err = _f32_rel_err(init["emit"], g["init"]["emit"])
+    margins = {"emit_max_rel": float(err.max()), "emit_frac_bit_identical": float((err == 0).mean())}
+    assert err.max() <= 1e-5 and (err == 0).mean() >= 0.99, margins
+    # after the trace: the reference's final records in, the reference's post-pass records as the expectation
+    want = g[f"post__{run}"]
+    rays = g[f"final__{run}"].copy()
+    lo, hi = float(np.float32(-np.pi)), float(np.float32(np.pi))
+    api.range_phi(rays, lo, hi)
+    assert (rays["phi"].view(np.int32) == want["phi"].view(np.int32)).all()
+    V, reverse, projradius = case["post"]
+    api.redshift(spin, V, reverse, projradius, rays)
+    api.calculate_momentum(spin, rays)
+    for f in ("t", "r", "theta", "k", "h", "Q", "emit", "alpha", "beta"):
+        assert (rays[f].view(np.int32) == want[f].view(np.int32)).all(), f            # untouched
+    for f in ("steps", "status", "rdot_sign", "thetadot_sign", "rdot_flips", "equatorial_crossings"):
+        assert (rays[f] == want[f]).all(), f
+    live = want["steps"] > 0
+    # measured on gfx950 (profiles/r02_parity_margins.json): every field of every ray carries the reference's bits -- the device's sinf /
+    # cosf / sqrtf / division round like glibc's on these inputs.  The bar leaves room for a last-bit libm difference on 1 % of the rays.
+    for f in ("redshift", "pt", "pr", "ptheta", "pphi"):
+        err = _f32_rel_err(rays[f], want[f])[live]
+        margins[f"{f}_frac_bit_identical"] = float((err == 0).mean())
+        margins[f"{f}_max_rel"] = float(err.max())
+        assert (err == 0).mean() >= 0.99 and np.median(err) == 0, (f, margins)
+    if f"postdest__{run}" in g.files:
+        api.redshift_dest(spin, reverse, rays)
+        err = _f32_rel_err(rays["redshift"], g[f"postdest__{run}"])[live]
+        margins["redshift_dest_frac_bit_identical"] = float((err == 0).mean())
+        assert (err == 0).mean() >= 0.99, margins
+    parity.record_margin("test_f32_passes_vs_reference_float", f"{case_name}-{run}", {"n_traced": int(live.sum()), "n_bad": 0, "frac_bad": 0.0, "worst_ok": None}, **margins)
+
+
 def test_degenerate_denominators_match_oracle(krlib):
     """Schwarzschild (a = 0) with a source on the axis region: h is ~0 for every ray, so phidot ~ 0 and the step
     heuristic divides by it; and a ray record placed exactly ON the pole (sin(theta) = 0).  Where IEEE division gives
