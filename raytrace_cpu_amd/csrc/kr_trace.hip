@@ -58,7 +58,10 @@ constexpr int kWavesPerBlock = kTraceBlock / 64;
 #ifndef KR_LONG_RAY_STEPS
 #define KR_LONG_RAY_STEPS 2048
 #endif
-constexpr int kCounters = 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps, [6] rk45 extrapolated steps
+#ifndef KR_OCC_STATS
+#define KR_OCC_STATS 0               // 1: lane-occupancy bookkeeping of the step loop (diagnostic builds: scripts/gpu_occ_stats.sh), printed by trace_wait
+#endif
+constexpr int kCounters = KR_OCC_STATS ? 12 : 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps, [6] rk45 extrapolated steps
 constexpr int kCounterBlocks = 4;    // main launch, strict side launch, strict overflow launch, split bookkeeping ([1] = number of ill-conditioned rays)
 constexpr int kListCap = 32768;      // index-list entries of the strict side launch (= 128 workgroups x 256 lanes, half of the chip)
 
@@ -171,12 +174,18 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
     unsigned prio_tick = 0;
 #endif
 
+#if KR_OCC_STATS
+    unsigned long long occ_iters = 0, occ_tail_iters = 0, occ_tail_steps = 0, occ_refills = 0, occ_refill_lanes = 0;
+#endif
     for (;;) {
         const unsigned long long need = __ballot(!have);
         const int n_need = __popcll(need);
         const bool any_have = (need != ~0ull);
 
         if (!exhausted && n_need > 0 && (n_need >= REFILL_MIN || !any_have)) {
+#if KR_OCC_STATS
+            ++occ_refills; occ_refill_lanes += n_need;
+#endif
             // wave-aggregated dequeue: one atomic for all free lanes
             const int leader = __ffsll((long long) need) - 1;
             unsigned long long base = 0;
@@ -248,6 +257,10 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
             // the tail of an RK45 launch is waves that hold nothing but creeping captured rays: they take 16 cheap steps per iteration
             if (!__any(have && !s.creep_mode)) replay_batch = 16;
         }
+#if KR_OCC_STATS
+        ++occ_iters;
+        if (exhausted) { ++occ_tail_iters; occ_tail_steps += have ? 1 : 0; }
+#endif
         if (have) {
             bool fin;
             if (METHOD == KR_EULER) fin = step_fixed<T, false, USE_DEST, FAST>(s, c);
@@ -269,6 +282,15 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
     const unsigned long long w_rej = wave_sum<T>((unsigned long long) my_rejects);
     const unsigned long long w_sta = wave_sum<T>((unsigned long long) my_stationary);
     const unsigned long long w_creep = wave_sum<T>((unsigned long long) my_creep);
+#if KR_OCC_STATS
+    {
+        const unsigned long long w_tail_steps = wave_sum<T>(occ_tail_steps);
+        if (lane == 0) {
+            atomicAdd(&counters[7], occ_iters); atomicAdd(&counters[8], occ_tail_iters); atomicAdd(&counters[9], w_tail_steps);
+            atomicAdd(&counters[10], occ_refills); atomicAdd(&counters[11], occ_refill_lanes);
+        }
+    }
+#endif
     if (lane == 0) {
         if (w_sta) atomicAdd(&counters[5], w_sta);
         if (w_creep) atomicAdd(&counters[6], w_creep);
@@ -983,6 +1005,14 @@ int trace_wait(void* ticket, kr_stats* stats)
         const unsigned long long* h2 = ws->h_counters;
         unsigned long long h[kCounters];
         for (int i = 0; i < kCounters; i++) h[i] = h2[i] + h2[kCounters + i] + h2[2 * kCounters + i];
+#if KR_OCC_STATS
+        for (int b = 0; b < 3; b++) {
+            const unsigned long long* q = h2 + b * kCounters;
+            if (q[7]) std::fprintf(stderr, "kr_occ: launch %d (0 main, 1 strict side, 2 overflow): steps %llu wave_iters %llu step-loop lane occupancy %.4f | after queue exhaustion: "
+                                   "wave_iters %llu (%.2f %%) lane occupancy %.4f | refills %llu lanes/refill %.2f\n", b, q[2], q[7], (double) q[2] / (64.0 * q[7]), q[8],
+                                   100.0 * q[8] / q[7], q[8] ? (double) q[9] / (64.0 * q[8]) : 0.0, q[10], q[10] ? (double) q[11] / q[10] : 0.0);
+        }
+#endif
         stats->rays_total = ws->n;
         stats->rays_strict_side = (int64_t) h2[3 * kCounters + 1];
         stats->rays_traced = (int64_t) h[1];
