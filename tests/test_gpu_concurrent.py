@@ -219,3 +219,37 @@ def test_merged_batch_is_bitwise_the_single_traces(krlib, flags, method, merged,
     finally:
         for b in bufs:
             b.free()
+
+
+def test_two_host_threads_trace_at_the_same_time(krlib):
+    """Two host threads, each with a host ray array of its own, inside kr_trace_f64 at the same time (ctypes drops the GIL for the
+    call): every call draws its own workspace, so each thread gets, bit for bit and counter for counter, what it gets alone.
+    (Round 1 kept one process-wide set of queue counters: ADVICE r01, 'shared DeviceScratch race'.)"""
+    import threading
+    specs = [bench.make_spec(capi, bench.grid_spacing_for(4.0e5)), bench.make_spec(capi, bench.grid_spacing_for(3.0e5))]
+    specs[1].pos[1] = 6.0
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, bench.R_MAX, capi.FLAG_HYBRID
+    inits = [api.pointsource_init(s) for s in specs]
+    alone = [api.trace(p, r) for r in inits]
+    assert all(st["rays_strict_side"] > 0 for _, st in alone)
+    errors = []
+
+    def worker(i):
+        try:
+            for rnd in range(3):
+                out, st = api.trace(p, inits[i])
+                if not same_bits(out, alone[i][0]):
+                    errors.append(f"thread {i} round {rnd}: rays differ")
+                for k in ("rays_traced", "steps_total", "rays_strict_side"):
+                    if st[k] != alone[i][1][k]:
+                        errors.append(f"thread {i} round {rnd}: {k} {st[k]} != {alone[i][1][k]}")
+        except Exception as e:                         # noqa: BLE001 -- reported through the list
+            errors.append(f"thread {i}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == []
