@@ -299,3 +299,81 @@ def test_return_radiation_full_size_properties(krlib):
     resc = parity.compare_rays(after, want, rtol=parity.RAY_RTOL, steps_slack=0)
     parity.record_margin("test_return_radiation_full_size_properties", "rr-radius37-euler-hybrid-sample", resc, parity.CHAOTIC_FRAC)
     assert resc["frac_bad"] <= parity.CHAOTIC_FRAC, resc
+
+
+def test_ray_buffer_beyond_4_gib(krlib):
+    """One ray buffer of 3.3e7 records = 4.75 GB (BASELINE sizes stay under 2^32 bytes: 1e7 x 144 = 1.44e9, 4097^2 x 144 = 2.4e9), so that
+    every kernel's record addressing is exercised past the 32-bit byte offset: source + redshift_start fused and separate, the hybrid trace,
+    the fused post pass and the separate ones.  Checks: a sample of rays from BEYOND the 4 GiB mark equals the oracle's trace of the same
+    input records; every valid ray was traced; fused and separate passes agree (bits / counts) over the whole buffer."""
+    lib = krlib
+    spec = _spec(1.99 / (math.sqrt(3.3e7) - 1.0))
+    n_rows, n_beta = C.c_int32(), C.c_int32()
+    n = lib.kr_pointsource_count(C.byref(spec), C.byref(n_rows), C.byref(n_beta))
+    assert n * 144 > (1 << 32) + (1 << 28)
+    first_beyond = (1 << 32) // 144 + 1
+    d_rays, d_hist = vp(), vp()
+    capi.check(lib, lib.kr_malloc(C.byref(d_rays), n * 144), "malloc")
+    bins = gc.emis_bins(spec, nr=100)
+    words = 5 * bins.nr + 1
+    capi.check(lib, lib.kr_malloc(C.byref(d_hist), words * 8), "malloc")
+
+    def fetch(idx):
+        out = np.zeros(len(idx), dtype=capi.RAY_F64)
+        for k, i in enumerate(idx):
+            capi.check(lib, lib.kr_memcpy_d2h(out[k:k + 1].ctypes.data_as(vp), vp(d_rays.value + int(i) * 144), 144), "d2h")
+        return out
+
+    def histogram():
+        h = np.zeros(words)
+        capi.check(lib, lib.kr_memcpy_d2h(h.ctypes.data_as(vp), d_hist, words * 8), "d2h")
+        return h
+
+    try:
+        rng = np.random.default_rng(4097)
+        idx = np.sort(rng.choice(np.arange(first_beyond, n), 1500, replace=False))
+        idx = np.unique(np.concatenate([idx, [first_beyond, n - 1, (n_rows.value - 2) * n_beta.value]]))      # + a beta = -pi ray (strict side launch)
+        p = capi.default_params(gc.SPIN)
+        p.integrator, p.r_max, p.flags = capi.RK4, 1000.0, capi.FLAG_HYBRID
+        # separate passes
+        capi.check(lib, lib.kr_pointsource_init_dev_f64(C.byref(spec), d_rays, n, None), "init")
+        capi.check(lib, lib.kr_redshift_start_dev_f64(gc.SPIN, 0.0, 0, 0, d_rays, n, None), "redshift_start")
+        before = fetch(idx)
+        st = capi.Stats()
+        capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, C.byref(st)), "trace")
+        assert st.rays_traced == n_rows.value * n_beta.value <= n          # (nRays is the truncated product of doubles: a few surplus slots stay unused)
+        assert st.rays_strict_side == n_rows.value                         # the beta = -pi column, one ray per row
+        after = fetch(idx)
+        want, _ = ol.oracle_trace(p, before)
+        res = parity.compare_rays(after, want, rtol=parity.RAY_RTOL, steps_slack=0)
+        parity.record_margin("test_ray_buffer_beyond_4_gib", "ps3.3e7-rk4-hybrid-sample-beyond-4GiB", res, parity.CHAOTIC_FRAC)
+        assert res["frac_bad"] <= parity.CHAOTIC_FRAC, res
+        assert (after["steps"][before["steps"] == 0] > 0).all()
+        capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, d_rays, n, None), "range_phi")
+        capi.check(lib, lib.kr_redshift_dev_f64(gc.SPIN, -1.0, 0, 0, 0, d_rays, n, None), "redshift")
+        capi.check(lib, lib.kr_memset(d_hist, 0, words * 8), "memset")
+        capi.check(lib, lib.kr_reduce_emissivity_dev_f64(C.byref(bins), d_rays, n, d_hist, None), "reduce")
+        sep_rays, sep_hist = fetch(idx), histogram()
+        # the two passes vs the oracle on the sampled (device-traced) records: one evaluation deep
+        want_post = after.copy()
+        ol.oracle().kro_range_phi_f64(-math.pi, math.pi, ol.ptr(want_post), len(want_post))
+        ol.oracle().kro_redshift_f64(gc.SPIN, -1.0, 0, 0, 0, ol.ptr(want_post), len(want_post))
+        assert ol.rays_equal_bitwise(sep_rays, want_post, fields=["phi"]) == []
+        live = (after["steps"] > 0) & np.isfinite(want_post["redshift"])
+        np.testing.assert_allclose(sep_rays["redshift"][live], want_post["redshift"][live], rtol=1e-10)
+        # fused passes over the same buffer
+        capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(spec), 0, 1, 0.0, 0, 0, d_rays, n, None), "init_emit")
+        assert ol.rays_equal_bitwise(fetch(idx), before) == []
+        st2 = capi.Stats()
+        capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, C.byref(st2)), "trace")
+        assert (st2.rays_traced, st2.steps_total, st2.rays_strict_side) == (st.rays_traced, st.steps_total, st.rays_strict_side)
+        capi.check(lib, lib.kr_memset(d_hist, 0, words * 8), "memset")
+        capi.check(lib, lib.kr_post_emissivity_dev_f64(gc.SPIN, -1.0, 0, 0, 0, -math.pi, math.pi, C.byref(bins), d_rays, n, d_hist, None), "post")
+        fused_rays, fused_hist = fetch(idx), histogram()
+        assert ol.rays_equal_bitwise(fused_rays, sep_rays) == []
+        assert sep_hist[5 * bins.nr] > 0.5 * n
+        np.testing.assert_array_equal(fused_hist[:bins.nr], sep_hist[:bins.nr])
+        np.testing.assert_allclose(fused_hist, sep_hist, rtol=1e-11)
+    finally:
+        lib.kr_free(d_rays)
+        lib.kr_free(d_hist)
