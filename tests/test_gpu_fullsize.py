@@ -377,3 +377,72 @@ def test_ray_buffer_beyond_4_gib(krlib):
     finally:
         lib.kr_free(d_rays)
         lib.kr_free(d_hist)
+
+
+def test_imageplane_buffer_beyond_4_gib(krlib):
+    """The same for the observer plane: 5801 x 5801 rays = 4.85 GB in one buffer, img 1024^2.  A sample of rays from beyond the 4 GiB mark
+    equals the oracle's trace of the same records; the fused ends (init + redshift_start, redshift + range_phi + planes) equal the
+    separate passes over the whole buffer (sampled records bit for bit, pixel counts exactly, plane sums to the order of the atomics)."""
+    lib = krlib
+    N, IMG = 5800, 1024
+    s = capi.ImagePlaneSpec()
+    s.dist, s.inc_deg, s.x0, s.xmax, s.y0, s.ymax = 10000.0, 80.0, -30.0, 30.0, -30.0, 30.0
+    s.dx = s.dy = 60.0 / N
+    s.spin, s.phi0, s.precision = gc.SPIN, 0.0, 100.0
+    total, nx, ny = api.imageplane_count(s)
+    assert total * 144 > (1 << 32) + (1 << 28)
+    first_beyond = (1 << 32) // 144 + 1
+    b = capi.ImageBins()
+    b.x0, b.y0, b.img_dx, b.img_dy = s.x0, s.y0, 60.0 / IMG, 60.0 / IMG
+    b.r_isco, b.r_disc = lib.kr_kerr_isco(gc.SPIN, 1), 30.0
+    b.q1, b.rb1, b.q2, b.rb2, b.q3 = 3.0, 4.0, 3.0, 10.0, 3.0
+    b.img_nx, b.img_ny, b.flip_image, b.pad = IMG, IMG, 1, 0
+    words = 7 * IMG * IMG + 1
+    npix = IMG * IMG
+    p = capi.default_params(-gc.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, 1.1 * s.dist, capi.FLAG_HYBRID
+    d_rays, d_pl = vp(), vp()
+    capi.check(lib, lib.kr_malloc(C.byref(d_rays), total * 144), "malloc")
+    capi.check(lib, lib.kr_malloc(C.byref(d_pl), words * 8), "malloc")
+
+    def planes():
+        out = np.zeros(words)
+        capi.check(lib, lib.kr_memcpy_d2h(out.ctypes.data_as(vp), d_pl, words * 8), "d2h")
+        return out
+
+    try:
+        rng = np.random.default_rng(5801)
+        idx = np.unique(np.concatenate([rng.choice(np.arange(first_beyond, total), 1200, replace=False), [first_beyond, total - 1]]))
+        # separate passes
+        capi.check(lib, lib.kr_imageplane_init_dev_f64(C.byref(s), d_rays, total, None), "init")
+        capi.check(lib, lib.kr_redshift_start_dev_f64(-gc.SPIN, 0.0, 1, 0, d_rays, total, None), "redshift_start")
+        before = _fetch(lib, d_rays, idx)
+        st = capi.Stats()
+        capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, total, None, C.byref(st)), "trace")
+        assert st.rays_traced == total and 0 < st.rays_strict_side < 3 * (N + 1)
+        after = _fetch(lib, d_rays, idx)
+        want, _ = ol.oracle_trace(p, before)
+        res = parity.compare_rays(after, want, rtol=parity.RAY_RTOL, steps_slack=0)
+        parity.record_margin("test_imageplane_buffer_beyond_4_gib", "ip5801-rk4-hybrid-sample-beyond-4GiB", res, parity.CHAOTIC_FRAC)
+        assert res["frac_bad"] <= parity.CHAOTIC_FRAC, res
+        capi.check(lib, lib.kr_redshift_dev_f64(-gc.SPIN, -1.0, 1, 0, 0, d_rays, total, None), "redshift")
+        capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, d_rays, total, None), "range_phi")
+        capi.check(lib, lib.kr_memset(d_pl, 0, words * 8), "memset")
+        capi.check(lib, lib.kr_reduce_image_dev_f64(C.byref(b), d_rays, total, d_pl, None), "reduce")
+        sep_rays, sep = _fetch(lib, d_rays, idx), planes()
+        # fused ends
+        capi.check(lib, lib.kr_imageplane_init_emit_dev_f64(C.byref(s), 0, 1, 0.0, 1, 0, d_rays, total, None), "init_emit")
+        assert ol.rays_equal_bitwise(_fetch(lib, d_rays, idx), before) == []
+        st2 = capi.Stats()
+        capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, total, None, C.byref(st2)), "trace")
+        assert (st2.rays_traced, st2.steps_total, st2.rays_strict_side) == (st.rays_traced, st.steps_total, st.rays_strict_side)
+        capi.check(lib, lib.kr_memset(d_pl, 0, words * 8), "memset")
+        capi.check(lib, lib.kr_post_image_dev_f64(-gc.SPIN, -1.0, 1, 0, 0, -math.pi, math.pi, C.byref(b), d_rays, total, d_pl, None), "post")
+        fused_rays, fused = _fetch(lib, d_rays, idx), planes()
+        assert ol.rays_equal_bitwise(fused_rays, sep_rays) == []
+        assert sep[-1] > 1e6 and sep[-1] == fused[-1] == sep[:npix].sum()
+        np.testing.assert_array_equal(fused[:npix], sep[:npix])
+        np.testing.assert_allclose(fused, sep, rtol=1e-11, atol=1e-300)
+    finally:
+        lib.kr_free(d_rays)
+        lib.kr_free(d_pl)
