@@ -349,6 +349,22 @@ KR_DEV double fast_rcp(double x)
     return y;
 }
 
+// One Newton step (relative error ~2^-46): for the step-size heuristic only, whose quotients end up under min() / as a step length
+// (a step that is 1e-14 longer moves the sample point along the same trajectory; the landing steps hit r_max / theta_max to 1e-16).
+#ifndef KR_HEURISTIC_RCP_SHORT
+#define KR_HEURISTIC_RCP_SHORT 1
+#endif
+KR_DEV double fast_rcp_heur(double x)
+{
+#if KR_HEURISTIC_RCP_SHORT
+    const double y = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+#else
+    return fast_rcp(x);
+#endif
+}
+KR_DEV float fast_rcp_heur(float x) { return fast_rcp(x); }
+
 KR_DEV double fast_sqrt(double x)      // sqrt(max(|x|, 1e-300)): rsq seed + one coupled Newton step + a residual correction
 {
     // The floor replaces the x == 0 / x == inf special cases of a plain rsq-based root (5 instructions per call, 8 calls per
@@ -599,16 +615,16 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         if (k1_with_flips_fast(s, a, aux)) return !(s.steps < c.steplim);
         pt1 = s.pt; pr1 = s.pr; ptheta1 = s.ptheta; pphi1 = s.pphi;
         // same heuristic, quotients as products with Newton-refined reciprocals
-        const T inv_pr = fast_rcp(pr1), inv_pth = fast_rcp(ptheta1);
+        const T inv_pr = fast_rcp_heur(pr1), inv_pth = fast_rcp_heur(ptheta1);
         const T q_th = kr_abs(s.theta * inv_pth);
         step = kr_abs((s.r - c.horizon) * inv_pr) * c.inv_precision;
         if (step > q_th * c.inv_precision) step = q_th * c.inv_theta_precision;
         if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
-            const T st = kr_abs(c.max_tstep * fast_rcp(pt1));
+            const T st = kr_abs(c.max_tstep * fast_rcp_heur(pt1));
             if (step > st) step = st;
         }
         if (c.max_phistep > 0) {
-            const T sp = kr_abs(c.max_phistep * fast_rcp(pphi1));
+            const T sp = kr_abs(c.max_phistep * fast_rcp_heur(pphi1));
             if (step > sp) step = sp;
         }
         if (step < KR_MIN_STEP) step = KR_MIN_STEP;
