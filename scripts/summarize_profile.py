@@ -4,12 +4,18 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-ks = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+def newest(pattern):
+    """gpurun merges every call's output into gpurun_out/: earlier runs of the same script leave their files (other PIDs) next to the new ones"""
+    fs = glob.glob(pattern)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
+ks = newest(f"{src}/trace/*/*_kernel_stats.csv")
 if ks:
     shutil.copy(ks[0], f"profiles/{tag}_kernel_stats.csv")
 summary = {"tag": tag, "command": "rocprofv3 --kernel-trace --stats / --pmc <group> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline (scripts/profile_round.sh)", "counters_per_trace_kernel_launch": {}}
 for d in sorted(glob.glob(f"{src}/pmc_*")):
-    fs = glob.glob(f"{d}/*/*_counter_collection.csv")
+    fs = newest(f"{d}/*/*_counter_collection.csv")
     if not fs: continue
     agg = collections.defaultdict(list); per = collections.defaultdict(lambda: collections.defaultdict(list)); meta = {}
     for row in csv.DictReader(open(fs[0])):
