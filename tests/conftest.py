@@ -13,8 +13,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def torch_hip_runtime_first():
+    """A process that uses both PyTorch-ROCm (which brings its own HIP runtime) and libkrtrace (linked against /opt/rocm's) must let
+    torch initialise first: the other way round torch.cuda finds "No HIP GPUs" (seen when test_gpu_fullsize.py ran on its own, its
+    torch-based return-radiation test after the ctypes-only ones).  bench.py does the same.  Without a GPU nothing is initialised."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+
+
 @pytest.fixture(scope="session")
-def krlib():
+def krlib(torch_hip_runtime_first):
     """The HIP shared library behind the C ABI; session-wide.  Fails (not skips) when it cannot be loaded."""
     from raytrace_cpu_amd import capi
     return capi.load()

@@ -82,7 +82,11 @@ def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False, steps_slack=2):
     for f in INT_FIELDS:
         int_bad |= live & (got[f] != want[f])
     term_bad = live & (terminal_bits(got["status"]) != terminal_bits(want["status"]))
-    return {"n_traced": n_live, "n_bad": int(bad.sum()), "frac_bad": float(bad.sum()) / max(n_live, 1), "worst_ok": worst,
+    # rays that carry the reference's bits in every compared output (t, r, theta, phi and the integer fields)
+    bits = live & ~int_bad & (got["steps"] == want["steps"])
+    for f in FLOAT_FIELDS:
+        bits &= (got[f].view(np.int64) == want[f].view(np.int64)) | (np.isnan(got[f]) & np.isnan(want[f]))
+    return {"frac_bit_identical": float(bits.sum()) / max(n_live, 1), "n_traced": n_live, "n_bad": int(bad.sum()), "frac_bad": float(bad.sum()) / max(n_live, 1), "worst_ok": worst,
             "n_steps_differ": int((live & (dsteps > 0)).sum()), "n_int_fields_differ": int(int_bad.sum()),
             "frac_terminal_status_differs": float(term_bad.sum()) / max(n_live, 1), "bad_index": np.flatnonzero(bad)}
 
@@ -152,6 +156,7 @@ _MARGINS = []
 
 def record_margin(test, case, res, allowed=None, envelope=None, **extra):
     row = {"test": test, "case": case, "n_traced": res["n_traced"], "n_bad": res["n_bad"], "frac_bad": res["frac_bad"], "worst_ok": res["worst_ok"],
+           "frac_bit_identical": res.get("frac_bit_identical"),
            "n_steps_differ": res.get("n_steps_differ"), "n_int_fields_differ": res.get("n_int_fields_differ"),
            "frac_terminal_status_differs": res.get("frac_terminal_status_differs"), "allowed_bad_frac": allowed, "noise_envelope_frac": envelope}
     row.update(extra)
