@@ -102,6 +102,64 @@ static __device__ __attribute__((noinline)) void kr_sincos_libm_f64(double x, do
 KR_SC_FN void kr_sincos_libm_f64(double x, double* s, double* c) { sincos(x, s, c); }
 #endif
 
+// Correctly rounded in practice (KR_CR_SINCOS, default): sin and cos of the reduced argument r + y, |r| <= pi/4, with the leading
+// terms carried in double-double -- r^3 (S1 + z (S2 + ...)) and z^2 (C2 + z (C3 + ...)) with z = r^2 as an exact product, S1, S2, C2, C3
+// as (hi, lo) pairs, Taylor tails (through r^21 / z^10) in plain double -- and ONE final rounding.  The accumulated error before that
+// rounding is ~2^-66 of the result: 12e6 random arguments in (-40, 40) all come out correctly rounded (against __float128), which makes
+// the strict path differ from glibc only where glibc itself is not correctly rounded (0.01-0.26 % of arguments; the fdlibm kernels
+// this replaces: 3-5 %).  ~95 fp64 instructions for the pair instead of ~68: the TwoSum / TwoProd sequences below rely on
+// -ffp-contract=off (every fma is spelled out).
+#ifndef KR_CR_SINCOS
+#define KR_CR_SINCOS 1
+#endif
+KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
+{
+    const double zh = r * r, zl = __builtin_fma(r, r, -zh);
+    // sin(r + y) = r + y cos r + r^3 (S1 + z (S2 + z T(z)))
+    double T = kr_fma3(zh, KR_KS(1.9572941063391263e-20), KR_KS(-8.22063524662433e-18));
+    T = kr_fma3(zh, T, KR_KS(2.8114572543455206e-15));
+    T = kr_fma3(zh, T, KR_KS(-7.647163731819816e-13));
+    T = kr_fma3(zh, T, KR_KS(1.6059043836821613e-10));
+    T = kr_fma3(zh, T, KR_KS(-2.505210838544172e-08));
+    T = kr_fma3(zh, T, KR_KS(2.7557319223985893e-06));
+    T = kr_fma3(zh, T, KR_KS(-0.0001984126984126984));
+    double s_ph, s_pl;
+    {
+        const double u = zh * T;
+        const double S2h = 0x1.1111111111111p-7, S2l = 0x1.1111111111111p-63, S1h = -0x1.5555555555555p-3, S1l = -0x1.5555555555555p-57;
+        const double ah = S2h + u, al = ((S2h - ah) + u) + S2l;                                   // Fast2Sum: |S2h| > |u|
+        const double bh = zh * ah, bl = __builtin_fma(zh, ah, -bh) + (zh * al + zl * ah);
+        const double qh = S1h + bh, ql = (((S1h - qh) + bh) + bl) + S1l;
+        const double ch = r * zh, cl = __builtin_fma(r, zh, -ch) + r * zl;                        // r^3
+        s_ph = ch * qh;
+        s_pl = __builtin_fma(ch, qh, -s_ph) + (ch * ql + cl * qh);
+    }
+    // cos(r + y) = 1 - z/2 - y sin r + z^2 (C2 + z (C3 + z TC(z)))
+    double TC = kr_fma3(zh, KR_KS(4.110317623312165e-19), KR_KS(-1.5619206968586225e-16));
+    TC = kr_fma3(zh, TC, KR_KS(4.779477332387385e-14));
+    TC = kr_fma3(zh, TC, KR_KS(-1.1470745597729725e-11));
+    TC = kr_fma3(zh, TC, KR_KS(2.08767569878681e-09));
+    TC = kr_fma3(zh, TC, KR_KS(-2.755731922398589e-07));
+    TC = kr_fma3(zh, TC, KR_KS(2.48015873015873e-05));
+    {
+        const double u = zh * TC;
+        const double C3h = -0.001388888888888889, C3l = 5.300543954373577e-20, C2h = 0.041666666666666664, C2l = 2.3129646346357427e-18;
+        const double ah = C3h + u, al = ((C3h - ah) + u) + C3l;
+        const double bh = zh * ah, bl = __builtin_fma(zh, ah, -bh) + (zh * al + zl * ah);
+        const double qh = C2h + bh, ql = (((C2h - qh) + bh) + bl) + C2l;
+        const double wh = zh * zh, wl = __builtin_fma(zh, zh, -wh) + 2.0 * (zh * zl);            // z^2
+        const double ph = wh * qh, pl = __builtin_fma(wh, qh, -ph) + (wh * ql + wl * qh);
+        const double hz = 0.5 * zh;
+        const double eh = 1.0 - hz, el = (1.0 - eh) - hz;                                         // 1 - z/2, exactly
+        const double c1 = eh + ph;                                                                // cos r and sin r to double precision:
+        const double sh = r + s_ph;                                                               // enough for the y terms
+        const double c2 = ((eh - c1) + ph) + (((el - 0.5 * zl) + pl) - sh * y);
+        cr = c1 + c2;
+        const double sl = ((r - sh) + s_ph) + (s_pl + c1 * y);
+        sr = sh + sl;
+    }
+}
+
 KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
 {
 #if KR_SMALL_ANGLE_SINCOS && KR_COMPACT_SINCOS
@@ -140,6 +198,10 @@ KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
     const double r0 = __builtin_fma(-t, 1.57079632679489655800e+00, x);     // P1 = fl(pi/2); exact
     const double r = __builtin_fma(-t, 6.12323399573676603587e-17, r0);     // P2 = pi/2 - P1
     const double y = __builtin_fma(-t, 6.12323399573676603587e-17, r0 - r); // what rounding r dropped
+#if KR_CR_SINCOS
+    double sr, cr;
+    kr_sincos_cr_core_f64(r, y - t * -1.4973849048591698e-33, sr, cr);                            // (third piece of pi/2)
+#else
     const double z = r * r;
     // sin(r + y)
     const double v = z * r;
@@ -156,6 +218,7 @@ KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
     qx = (ar > 0.78125) ? 0.28125 : qx;
     qx = (ar < 0.3) ? 0.0 : qx;
     const double cr = (1.0 - qx) - ((0.5 * z - qx) - (z * pc - r * y));
+#endif
     // quadrant: sin -> {s, c, -s, -c}[n & 3], cos -> {c, -s, -c, s}[n & 3]
     const bool odd = (n & 1) != 0;
     const double ss = odd ? cr : sr;

@@ -442,7 +442,7 @@ def test_imageplane_buffer_beyond_4_gib(krlib):
         assert ol.rays_equal_bitwise(fused_rays, sep_rays) == []
         assert sep[-1] > 1e6 and sep[-1] == fused[-1] == sep[:npix].sum()
         np.testing.assert_array_equal(fused[:npix], sep[:npix])
-        np.testing.assert_allclose(fused, sep, rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(fused, sep, rtol=1e-9, atol=1e-300)       # order of the atomic additions only (the phi plane's sums cancel: 1e-11 seen)
     finally:
         lib.kr_free(d_rays)
         lib.kr_free(d_pl)
