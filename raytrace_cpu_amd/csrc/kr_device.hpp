@@ -107,11 +107,14 @@ KR_DEV bool kr_finite(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 
 KR_DEV double kr_sqrt(double x) { return __builtin_sqrt(x); }
 KR_DEV float kr_sqrt(float x) { return __builtin_sqrtf(x); }
-KR_DEV void kr_sincos(double x, double& s, double& c) { kr_sincos_f64(x, s, c); }
-KR_DEV void kr_sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
-KR_DEV double kr_sin(double x) { return ::sin(x); }
+// CR: the correctly rounded strict routine (default) or the shorter < 1-ulp one (the RK45 bodies: kr_sincos.hpp::kr_sincos_t)
+template <bool CR = true> KR_DEV void kr_sincos(double x, double& s, double& c) { kr_sincos_t<CR && (KR_CR_SINCOS != 0)>(x, s, c); }
+template <bool CR = true> KR_DEV void kr_sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+// double: the strict path's own correctly rounded pair (kr_sincos.hpp) instead of the device libm (<= 1 ulp): the O(N) passes, the ray sources
+// and the FlatPlane stop test then differ from glibc only where glibc is not correctly rounded; the unused half is dead code
+KR_DEV double kr_sin(double x) { double s, c; kr_sincos_t<(KR_CR_SINCOS != 0)>(x, s, c); return s; }
 KR_DEV float kr_sin(float x) { return ::sinf(x); }
-KR_DEV double kr_cos(double x) { return ::cos(x); }
+KR_DEV double kr_cos(double x) { double s, c; kr_sincos_t<(KR_CR_SINCOS != 0)>(x, s, c); return c; }
 KR_DEV float kr_cos(float x) { return ::cosf(x); }
 KR_DEV double kr_tan(double x) { return ::tan(x); }
 KR_DEV float kr_tan(float x) { return ::tanf(x); }
@@ -201,11 +204,11 @@ template <typename T> struct Lane {
 };
 
 // momentum_from_consts, src/include/kerr.h:300-335
-template <typename T, bool LEAN>
+template <typename T, bool LEAN, bool CR_SINCOS = true>
 KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a, Lane<T>* keep = nullptr)
 {
     T sin_theta, cos_theta;
-    kr_sincos(theta, sin_theta, cos_theta);
+    kr_sincos<CR_SINCOS>(theta, sin_theta, cos_theta);
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
@@ -245,7 +248,7 @@ KR_DEV bool k1_impl(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
 {
     const T r = s.r, theta = s.theta, k = s.k, h = s.h;
     T sin_theta, cos_theta;
-    kr_sincos(theta, sin_theta, cos_theta);
+    kr_sincos<!RK45_ASSOC>(theta, sin_theta, cos_theta);          // (RK45_ASSOC <=> called from the RK45 bodies)
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
@@ -517,11 +520,11 @@ KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
 }
 
 // one derivative evaluation on either path
-template <typename T, bool FAST>
+template <typename T, bool FAST, bool CR_SINCOS = true>
 KR_DEV void eval(T& pt, T& pr, T& ptheta, T& pphi, const Lane<T>& s, T r, T theta, T a)
 {
     if constexpr (FAST) momentum_fast(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r, theta, a);
-    else momentum(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r, theta, a);
+    else momentum_impl<T, LeanDefault<T>::value, CR_SINCOS>(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r, theta, a);
 }
 
 // loop condition of the theta-limit overloads (raytracer.cpp:172, :799, :1362-1364) or of the
@@ -756,7 +759,7 @@ KR_DEV void rk45_seed(Lane<T>& s, const TraceConsts<T>& c)
 {
     const T a = c.a, r = s.r, theta = s.theta, k = s.k, h = s.h;
     T sin_theta, cos_theta;
-    kr_sincos(theta, sin_theta, cos_theta);
+    kr_sincos<false>(theta, sin_theta, cos_theta);
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
@@ -929,27 +932,27 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T pr2, ptheta2, pr3, ptheta3, pr4, ptheta4, pr5, ptheta5, pr6, ptheta6;
     T sum_t = D::b1 * pt1, sum_phi = D::b1 * pphi1;
 
-    eval<T, FAST>(pt_i, pr2, ptheta2, pphi_i, s, r + h_try * D::a21 * pr1,
+    eval<T, FAST, false>(pt_i, pr2, ptheta2, pphi_i, s, r + h_try * D::a21 * pr1,
              theta + h_try * D::a21 * ptheta1, a);
 
-    eval<T, FAST>(pt_i, pr3, ptheta3, pphi_i, s, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
+    eval<T, FAST, false>(pt_i, pr3, ptheta3, pphi_i, s, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
              theta + h_try * (D::a31 * ptheta1 + D::a32 * ptheta2), a);
     sum_t = sum_t + D::b3 * pt_i;
     sum_phi = sum_phi + D::b3 * pphi_i;
 
-    eval<T, FAST>(pt_i, pr4, ptheta4, pphi_i, s,
+    eval<T, FAST, false>(pt_i, pr4, ptheta4, pphi_i, s,
              r + h_try * (D::a41 * pr1 + D::a42 * pr2 + D::a43 * pr3),
              theta + h_try * (D::a41 * ptheta1 + D::a42 * ptheta2 + D::a43 * ptheta3), a);
     sum_t = sum_t + D::b4 * pt_i;
     sum_phi = sum_phi + D::b4 * pphi_i;
 
-    eval<T, FAST>(pt_i, pr5, ptheta5, pphi_i, s,
+    eval<T, FAST, false>(pt_i, pr5, ptheta5, pphi_i, s,
              r + h_try * (D::a51 * pr1 + D::a52 * pr2 + D::a53 * pr3 + D::a54 * pr4),
              theta + h_try * (D::a51 * ptheta1 + D::a52 * ptheta2 + D::a53 * ptheta3 + D::a54 * ptheta4), a);
     sum_t = sum_t + D::b5 * pt_i;
     sum_phi = sum_phi + D::b5 * pphi_i;
 
-    eval<T, FAST>(pt_i, pr6, ptheta6, pphi_i, s,
+    eval<T, FAST, false>(pt_i, pr6, ptheta6, pphi_i, s,
              r + h_try * (D::a61 * pr1 + D::a62 * pr2 + D::a63 * pr3 + D::a64 * pr4 + D::a65 * pr5),
              theta + h_try * (D::a61 * ptheta1 + D::a62 * ptheta2 + D::a63 * ptheta3 + D::a64 * ptheta4 + D::a65 * ptheta5), a);
     sum_t = sum_t + D::b6 * pt_i;
@@ -968,9 +971,9 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T pt7, pr7, ptheta7, pphi7;
     Lane<T> last;                   // (only its f_* members are written, and only on the strict double path)
     if constexpr (!FAST && sizeof(T) == 8)
-        momentum_impl<T, LeanDefault<T>::value>(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a, &last);
+        momentum_impl<T, LeanDefault<T>::value, false>(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a, &last);
     else
-        eval<T, FAST>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
+        eval<T, FAST, false>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
 
     // error norm over (r, theta) and the step controller (:1508-1519)
     const T err_r = h_try * (D::e1 * pr1 + D::e3 * pr3 + D::e4 * pr4 + D::e5 * pr5 + D::e6 * pr6 + D::e7 * pr7);

@@ -88,7 +88,7 @@ KR_SC_FN void kr_sincos_small_f64(double x, double& s, double& c)
     c = 1.0 + __builtin_fma(z * z, pc, -0.5 * z);
 }
 
-KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c);
+template <bool CR> KR_SC_FN void kr_sincos_general_t(double x, double& s, double& c);
 
 // |x| >= 1024 and non-finite arguments (never reached by a healthy ray): the library routine, OUT OF LINE.  Inlined it is ~1 KB of
 // Payne-Hanek code per call site -- 9 KB of the RK45 kernels, 4 KB of the RK4 ones -- and the instruction cache (64 KB per two CUs)
@@ -160,7 +160,11 @@ KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
     }
 }
 
-KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
+// CR: the correctly rounded general kernel (fixed-step integrators, O(N) passes) or the fdlibm kernels (RK45: its parity is set by the step
+// controller's pow, and the wave of its longest ray pays for every instruction of the general branch whenever one lane leaves the small-angle regime:
+// 1e7 rays 0.38 -> 0.41 s with the longer routine, profiles/r02_ab_experiments.txt).  A compile-time property of the caller, so a ray still gets the
+// same bits in whichever kernel / wave of ITS integrator it is traced.
+template <bool CR> KR_SC_FN void kr_sincos_t(double x, double& s, double& c)
 {
 #if KR_SMALL_ANGLE_SINCOS && KR_COMPACT_SINCOS
     const bool small = __builtin_fabs(x) < KR_SMALL_ANGLE_LIMIT;
@@ -169,7 +173,7 @@ KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
         kr_sincos_small_f64(x, s, c);
         return;
     }
-    kr_sincos_general_f64(x, s, c);
+    kr_sincos_general_t<CR>(x, s, c);
     if (__builtin_amdgcn_ballot_w64(small) != 0) {       // mixed wave
         double s1, c1;
         kr_sincos_small_f64(x, s1, c1);
@@ -178,14 +182,16 @@ KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
     }
 #else
     if (small) kr_sincos_small_f64(x, s, c);
-    else kr_sincos_general_f64(x, s, c);
+    else kr_sincos_general_t<CR>(x, s, c);
 #endif
 #else
-    kr_sincos_general_f64(x, s, c);
+    kr_sincos_general_t<CR>(x, s, c);
 #endif
 }
 
-KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
+KR_SC_FN void kr_sincos_f64(double x, double& s, double& c) { kr_sincos_t<(KR_CR_SINCOS != 0)>(x, s, c); }
+
+template <bool CR> KR_SC_FN void kr_sincos_general_t(double x, double& s, double& c)
 {
 #if KR_COMPACT_SINCOS
     const double ax = __builtin_fabs(x);
@@ -198,16 +204,16 @@ KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
     const double r0 = __builtin_fma(-t, 1.57079632679489655800e+00, x);     // P1 = fl(pi/2); exact
     const double r = __builtin_fma(-t, 6.12323399573676603587e-17, r0);     // P2 = pi/2 - P1
     const double y = __builtin_fma(-t, 6.12323399573676603587e-17, r0 - r); // what rounding r dropped
-#if KR_CR_SINCOS
     double sr, cr;
+    if constexpr (CR) {
     kr_sincos_cr_core_f64(r, y - t * -1.4973849048591698e-33, sr, cr);                            // (third piece of pi/2)
-#else
+    } else {
     const double z = r * r;
     // sin(r + y)
     const double v = z * r;
     const double ps = kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, KR_KS(1.58969099521155010221e-10), KR_KS(-2.50507602534068634195e-08)),
                                                           KR_KS(2.75573137070700676789e-06)), KR_KS(-1.98412698298579493134e-04)), KR_KS(8.33333333332248946124e-03));
-    const double sr = r - ((z * (0.5 * y - v * ps) - y) - v * -1.66666666666666324348e-01);
+    sr = r - ((z * (0.5 * y - v * ps) - y) - v * -1.66666666666666324348e-01);
     // cos(r + y)
     const double pc = z * kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, KR_KS(-1.13596475577881948265e-11), KR_KS(2.08757232129817482790e-09)),
                                                                       KR_KS(-2.75573143513906633035e-07)), KR_KS(2.48015872894767294178e-05)), KR_KS(-1.38888888888741095749e-03)), KR_KS(4.16666666666666019037e-02));
@@ -217,8 +223,8 @@ KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
     double qx = __builtin_bit_cast(double, qbits);
     qx = (ar > 0.78125) ? 0.28125 : qx;
     qx = (ar < 0.3) ? 0.0 : qx;
-    const double cr = (1.0 - qx) - ((0.5 * z - qx) - (z * pc - r * y));
-#endif
+    cr = (1.0 - qx) - ((0.5 * z - qx) - (z * pc - r * y));
+    }
     // quadrant: sin -> {s, c, -s, -c}[n & 3], cos -> {c, -s, -c, s}[n & 3]
     const bool odd = (n & 1) != 0;
     const double ss = odd ? cr : sr;

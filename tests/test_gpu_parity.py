@@ -60,6 +60,10 @@ def test_trace_vs_golden(krlib, case_name, run, flags):
     parity.record_margin("test_trace_vs_golden", f"{case_name}-{run}-{mode}", res, allowed, envelope)
     assert res["n_traced"] > 0
     assert res["frac_bad"] <= allowed, res
+    if flags == 0 and params.integrator != capi.RK45:
+        # strict arithmetic, fixed step: sin / cos are correctly rounded, everything else is IEEE -- nearly every ray carries the reference's bits in
+        # every output (measured: PointSource 99.7-100 %, image plane 96.5-98.4 %: the rest is where glibc's own sin / cos is not correctly rounded)
+        assert res["frac_bit_identical"] >= (0.95 if gc.is_imageplane(case) else 0.99), res["frac_bit_identical"]
     if parity.is_unconverged_endpoint(params):
         # end positions are ill-conditioned in the reference itself; what a ray DID (hit the plane / escaped / fell in) is not
         assert res["frac_terminal_status_differs"] <= 0.01, res
