@@ -158,6 +158,10 @@ def test_source_init_and_redshift_start(krlib, case_name):
         ok = live & ~(np.isnan(want[f]))
         np.testing.assert_allclose(rays[f][ok], want[f][ok], rtol=1e-11, atol=1e-13, err_msg=f)
         assert np.isnan(rays[f][live & np.isnan(want[f])]).all(), f
+    # how many records carry the reference's bits (what is left: acos / atan2 of the device library, glibc's last-bit choices in sin / cos)
+    same = {f: float((rays[f][live].view(np.int64) == want[f][live].view(np.int64)).mean()) for f in ("k", "h", "Q", "emit", "theta", "phi")}
+    parity.record_margin("test_source_init_and_redshift_start", case_name, {"n_traced": int(live.sum()), "n_bad": 0, "frac_bad": 0.0, "worst_ok": None},
+                         **{f"frac_bit_identical_{f}": v for f, v in same.items()})
 
 
 def test_redshift_variants_vs_oracle(krlib):
