@@ -107,7 +107,14 @@ KR_DEV bool kr_finite(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 
 KR_DEV double kr_sqrt(double x) { return __builtin_sqrt(x); }
 KR_DEV float kr_sqrt(float x) { return __builtin_sqrtf(x); }
-// CR: the correctly rounded strict routine (default) or the shorter < 1-ulp one (the RK45 bodies: kr_sincos.hpp::kr_sincos_t)
+// CR: the correctly rounded strict routine (default) or the shorter < 1-ulp one (kr_sincos.hpp::kr_sincos_t).  KR_RK45_CR_SINCOS: which of the
+// two the RK45 bodies use.  1 (default): with the correctly rounded controller root below, 96-99 % of a PointSource's strict RK45 rays carry the
+// reference's bits in every output (short kernels: 80-90 %; before either: 67-71 %) and the rest agree to 1e-10 instead of 7e-8; costs 7 % of a
+// 1e7-ray RK45 launch (380 -> 406 ms: the longest ray's 1e5 steps each evaluate seven sin/cos pairs).
+#ifndef KR_RK45_CR_SINCOS
+#define KR_RK45_CR_SINCOS 1
+#endif
+constexpr bool kRk45CrSincos = (KR_RK45_CR_SINCOS != 0);
 template <bool CR = true> KR_DEV void kr_sincos(double x, double& s, double& c) { kr_sincos_t<CR && (KR_CR_SINCOS != 0)>(x, s, c); }
 template <bool CR = true> KR_DEV void kr_sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
 // double: the strict path's own correctly rounded pair (kr_sincos.hpp) instead of the device libm (<= 1 ulp): the O(N) passes, the ray sources
@@ -125,7 +132,7 @@ KR_DEV float kr_pow(float x, float y) { return ::powf(x, y); }
 // [0.1, 5]).  The clamp makes the root matter only for x in [1.7e-5, 5.3e3]; x is first brought into [1e-6, 1e6], which
 // cannot change the clamped factor, so that a single-precision seed is always in range.  Seed from the hardware log2 / exp2
 // (~1e-7), two Newton steps y <- y (4 + x / y^5) / 5 (error 2 e^2 each) a residual correction and the factor that
-// turns the exact root into x^0.2 with the double constant 0.2: <= 1 ulp of pow(x, 0.2) (tests/test_gpu_primitives.py), ~35 instructions against ~200 for the library pow.  NaN in, NaN out.
+// turns the exact root into x^0.2 with the double constant 0.2, correctly rounded (tests/test_gpu_primitives.py), ~45 instructions against ~200 for the library pow.  NaN in, NaN out.
 #ifndef KR_FIFTH_ROOT
 #define KR_FIFTH_ROOT 1
 #endif
@@ -141,12 +148,15 @@ KR_DEV double fifth_root_for_controller(double x)
         const double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
         y = y * __builtin_fma(x, lean_div(1.0, y5), 4.0) * 0.2;
     }
-    // one more Newton step written as a correction, so that the last rounding is of a small term
-    const double y2 = y * y, y4 = y2 * y2;
-    const double r = __builtin_fma(-y4, y, x);                  // x - y^5, the last product unrounded
-    y = __builtin_fma(r, lean_div(0.2, y4), y);
-    // the reference raises to the DOUBLE 0.2 = 1/5 + 1.11e-17, not to 1/5: x^0.2 = x^(1/5) (1 + 1.11e-17 ln x), up to 0.7 ulp here
-    return __builtin_fma(y, 7.695479593116622e-18 * (double) lg, y);       // 1.1102230246251565e-17 * ln 2 * log2 x
+    // Last step in double-double: y^5 as an exact product chain, the residual x - y^5 exactly (the leading parts cancel), then ONE rounding of
+    // y + (correction + exponent term).  The reference raises to the DOUBLE 0.2 = 1/5 + 1.11e-17, not to 1/5: x^0.2 = x^(1/5) (1 + 1.11e-17 ln x).
+    // Correctly rounded on 3e6 random arguments (against __float128 powq); glibc's pow agrees with that on 99.9 %.
+    const double y2h = y * y, y2l = __builtin_fma(y, y, -y2h);
+    const double y4h = y2h * y2h, y4l = __builtin_fma(y2h, y2h, -y4h) + 2.0 * (y2h * y2l);
+    const double y5h = y4h * y, y5l = __builtin_fma(y4h, y, -y5h) + y4l * y;
+    const double r = (x - y5h) - y5l;
+    const double corr = r * lean_div(0.2, y4h);
+    return y + __builtin_fma(y, 7.695479593116622e-18 * (double) lg, corr);       // 1.1102230246251565e-17 * ln 2 * log2 x
 #else
     return ::pow(x, 0.2);
 #endif
@@ -248,7 +258,7 @@ KR_DEV bool k1_impl(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
 {
     const T r = s.r, theta = s.theta, k = s.k, h = s.h;
     T sin_theta, cos_theta;
-    kr_sincos<!RK45_ASSOC>(theta, sin_theta, cos_theta);          // (RK45_ASSOC <=> called from the RK45 bodies)
+    kr_sincos<(!RK45_ASSOC || kRk45CrSincos)>(theta, sin_theta, cos_theta);          // (RK45_ASSOC <=> called from the RK45 bodies)
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
@@ -759,7 +769,7 @@ KR_DEV void rk45_seed(Lane<T>& s, const TraceConsts<T>& c)
 {
     const T a = c.a, r = s.r, theta = s.theta, k = s.k, h = s.h;
     T sin_theta, cos_theta;
-    kr_sincos<false>(theta, sin_theta, cos_theta);
+    kr_sincos<kRk45CrSincos>(theta, sin_theta, cos_theta);
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
@@ -932,27 +942,27 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T pr2, ptheta2, pr3, ptheta3, pr4, ptheta4, pr5, ptheta5, pr6, ptheta6;
     T sum_t = D::b1 * pt1, sum_phi = D::b1 * pphi1;
 
-    eval<T, FAST, false>(pt_i, pr2, ptheta2, pphi_i, s, r + h_try * D::a21 * pr1,
+    eval<T, FAST, kRk45CrSincos>(pt_i, pr2, ptheta2, pphi_i, s, r + h_try * D::a21 * pr1,
              theta + h_try * D::a21 * ptheta1, a);
 
-    eval<T, FAST, false>(pt_i, pr3, ptheta3, pphi_i, s, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
+    eval<T, FAST, kRk45CrSincos>(pt_i, pr3, ptheta3, pphi_i, s, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
              theta + h_try * (D::a31 * ptheta1 + D::a32 * ptheta2), a);
     sum_t = sum_t + D::b3 * pt_i;
     sum_phi = sum_phi + D::b3 * pphi_i;
 
-    eval<T, FAST, false>(pt_i, pr4, ptheta4, pphi_i, s,
+    eval<T, FAST, kRk45CrSincos>(pt_i, pr4, ptheta4, pphi_i, s,
              r + h_try * (D::a41 * pr1 + D::a42 * pr2 + D::a43 * pr3),
              theta + h_try * (D::a41 * ptheta1 + D::a42 * ptheta2 + D::a43 * ptheta3), a);
     sum_t = sum_t + D::b4 * pt_i;
     sum_phi = sum_phi + D::b4 * pphi_i;
 
-    eval<T, FAST, false>(pt_i, pr5, ptheta5, pphi_i, s,
+    eval<T, FAST, kRk45CrSincos>(pt_i, pr5, ptheta5, pphi_i, s,
              r + h_try * (D::a51 * pr1 + D::a52 * pr2 + D::a53 * pr3 + D::a54 * pr4),
              theta + h_try * (D::a51 * ptheta1 + D::a52 * ptheta2 + D::a53 * ptheta3 + D::a54 * ptheta4), a);
     sum_t = sum_t + D::b5 * pt_i;
     sum_phi = sum_phi + D::b5 * pphi_i;
 
-    eval<T, FAST, false>(pt_i, pr6, ptheta6, pphi_i, s,
+    eval<T, FAST, kRk45CrSincos>(pt_i, pr6, ptheta6, pphi_i, s,
              r + h_try * (D::a61 * pr1 + D::a62 * pr2 + D::a63 * pr3 + D::a64 * pr4 + D::a65 * pr5),
              theta + h_try * (D::a61 * ptheta1 + D::a62 * ptheta2 + D::a63 * ptheta3 + D::a64 * ptheta4 + D::a65 * ptheta5), a);
     sum_t = sum_t + D::b6 * pt_i;
@@ -971,9 +981,9 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T pt7, pr7, ptheta7, pphi7;
     Lane<T> last;                   // (only its f_* members are written, and only on the strict double path)
     if constexpr (!FAST && sizeof(T) == 8)
-        momentum_impl<T, LeanDefault<T>::value, false>(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a, &last);
+        momentum_impl<T, LeanDefault<T>::value, kRk45CrSincos>(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a, &last);
     else
-        eval<T, FAST, false>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
+        eval<T, FAST, kRk45CrSincos>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
 
     // error norm over (r, theta) and the step controller (:1508-1519)
     const T err_r = h_try * (D::e1 * pr1 + D::e3 * pr3 + D::e4 * pr4 + D::e5 * pr5 + D::e6 * pr6 + D::e7 * pr7);

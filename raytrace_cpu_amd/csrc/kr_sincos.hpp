@@ -160,9 +160,8 @@ KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
     }
 }
 
-// CR: the correctly rounded general kernel (fixed-step integrators, O(N) passes) or the fdlibm kernels (RK45: its parity is set by the step
-// controller's pow, and the wave of its longest ray pays for every instruction of the general branch whenever one lane leaves the small-angle regime:
-// 1e7 rays 0.38 -> 0.41 s with the longer routine, profiles/r02_ab_experiments.txt).  A compile-time property of the caller, so a ray still gets the
+// CR: the correctly rounded general kernel (default everywhere) or the shorter fdlibm kernels (kept for A/B builds: -DKR_RK45_CR_SINCOS=0 gives the
+// RK45 bodies the short ones, 1e7 rays 0.41 -> 0.38 s; profiles/r02_ab_experiments.txt).  A compile-time property of the caller, so a ray gets the
 // same bits in whichever kernel / wave of ITS integrator it is traced.
 template <bool CR> KR_SC_FN void kr_sincos_t(double x, double& s, double& c)
 {

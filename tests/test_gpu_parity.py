@@ -64,6 +64,10 @@ def test_trace_vs_golden(krlib, case_name, run, flags):
         # strict arithmetic, fixed step: sin / cos are correctly rounded, everything else is IEEE -- nearly every ray carries the reference's bits in
         # every output (measured: PointSource 99.7-100 %, image plane 96.5-98.4 %: the rest is where glibc's own sin / cos is not correctly rounded)
         assert res["frac_bit_identical"] >= (0.95 if gc.is_imageplane(case) else 0.99), res["frac_bit_identical"]
+    if flags == 0 and params.integrator == capi.RK45 and not gc.is_imageplane(case):
+        # strict RK45 from a PointSource: sin / cos and the controller's root are correctly rounded -> measured 96-99 % bit-identical, the rays
+        # that are not "bad" within 1e-10 (the bad ones are the NaN-ending polar rays, whose step of death is rounding-decided in the reference)
+        assert res["frac_bit_identical"] >= 0.93 and res["worst_ok"] <= 1e-9, (res["frac_bit_identical"], res["worst_ok"])
     if parity.is_unconverged_endpoint(params):
         # end positions are ill-conditioned in the reference itself; what a ray DID (hit the plane / escaped / fell in) is not
         assert res["frac_terminal_status_differs"] <= 0.01, res
