@@ -558,6 +558,8 @@ def main():
     for _ in range(args.steps):
         st = one_step()
         kernel_ms.append(st["kernel_ms"])
+        if os.environ.get("KR_BENCH_VERBOSE"):
+            print(f"step: kernel_ms {st['kernel_ms']:.1f} strict_side {st.get('strict_side_ms', 0):.1f} main {st.get('main_ms', 0):.1f}", file=sys.stderr, flush=True)
         steps_total, traced, stats_last = st["steps_total"], st["rays_traced"], st
     fence()
     elapsed = time.perf_counter() - t0
