@@ -164,6 +164,18 @@ def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
     rays_check = {"rays": n_valid, "integer_fields_differ": int((valid & ~ints_same).sum()),
                   "disc_rays": int(on_disc.sum()), "disc_rays_beyond_1e-9": int((on_disc & ints_same & ~close).sum()),
                   "bit_identical_r_theta_frac": float(((gpu_rays["r"] == cpu_rays["r"]) & (gpu_rays["theta"] == cpu_rays["theta"]))[valid].mean())}
+    # the same sample once more on the strict arithmetic (IEEE + - x / sqrt, correctly rounded sin / cos): how many rays carry the CPU's bits
+    # in EVERY output of the trace + redshift (what the hybrid launch gives its flagged rays; all rays with --arithmetic strict)
+    p.flags = 0
+    strict_rays, _ = api.trace(p, init)
+    api.range_phi(strict_rays)
+    api.redshift(SPIN, -1.0, 0, 0, strict_rays)
+    bits = valid.copy()
+    for k in ("t", "r", "theta", "phi", "redshift"):
+        bits &= (strict_rays[k].view(np.int64) == cpu_rays[k].view(np.int64)) | (np.isnan(strict_rays[k]) & np.isnan(cpu_rays[k]))
+    for k in ("status", "rdot_flips", "equatorial_crossings", "steps"):
+        bits &= strict_rays[k] == cpu_rays[k]
+    rays_check["strict_arithmetic_bit_identical_frac(t, r, theta, phi, redshift, integer fields)"] = float(bits[valid].mean())
     unit = "rays/s"
     return {
         "value": n_valid / wall, "unit": unit, "cores": cores, "kind": kind,
