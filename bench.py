@@ -711,9 +711,20 @@ def cpu_baseline_imageplane(args, capi, api, wl):
     ints_differ = 0
     for k in ("status", "rdot_flips", "equatorial_crossings", "steps"):
         ints_differ += int((gpu[k] != out[k]).sum())
+    # the strict arithmetic on the same rays: how many carry the CPU's bits in every output of trace + redshift + range_phi
+    strict, _ = api.trace(capi.copy_params(p, flags=0), init)
+    api.redshift(-SPIN, -1.0, 1, 0, strict)
+    api.range_phi(strict)
+    bits = live.copy()
+    for k in ("t", "r", "theta", "phi", "redshift"):
+        bits &= (strict[k].view(np.int64) == out[k].view(np.int64)) | (np.isnan(strict[k]) & np.isnan(out[k]))
+    for k in ("status", "rdot_flips", "equatorial_crossings", "steps"):
+        bits &= strict[k] == out[k]
+    strict_bits = float(bits[live].mean())
     planes_check = {"image": f"{img}x{img}", "lit_pixels": int((w_n > 0).sum()), "pixels_count_mismatch": int((~same).sum()), "disc_rays_cpu": int(dc.value),
                     "disc_rays_gpu": int(got["disc_count"]), "max_rel_diff_of_pixel_sums(RADIUS, ENSHIFT, FLUX, TIME)": worst, "tolerance": 1e-6,
-                    "ray_integer_fields_differ": ints_differ}
+                    "ray_integer_fields_differ": ints_differ,
+                    "strict_arithmetic_bit_identical_frac(t, r, theta, phi, redshift, integer fields)": strict_bits}
     return {"value": int(live.sum()) / wall, "unit": "rays/s", "cores": cores, "kind": kind, "steps_per_sec": steps / wall, "wall_s": wall,
             "sample": f"same image plane on a {N + 1}x{N + 1} ray grid: {int(live.sum())} rays, {steps} steps, run_raytrace only",
             "planes_check": planes_check}
