@@ -1,6 +1,6 @@
 """GPU: the arithmetic primitives of the trace kernel, one at a time, against the host's IEEE results.
 The strict path's claim is: + - * are IEEE, division and square root are CORRECTLY ROUNDED (bit-equal to numpy),
-sin/cos are the only place the device differs from the CPU (<= 1 ulp from glibc)."""
+sin/cos are correctly rounded in practice, i.e. the device differs from the CPU only where glibc itself is not (<= 0.3 % of arguments)."""
 import ctypes as C
 
 import numpy as np
@@ -76,7 +76,7 @@ def test_compact_sincos_within_one_ulp_of_glibc(krlib):
     for op, f in ((4, np.sin), (5, np.cos)):
         u = ulps(probe(op, x), f(x))
         assert u.max() <= 1.0, (op, u.max())
-        assert (u == 0).mean() > 0.95
+        assert (u == 0).mean() > 0.997          # correctly rounded on the device: what differs is where the host libm is not (measured 99.8-99.99 %)
     # far outside the polar-angle range and for non-finite input the library path answers
     big = np.array([1e5, -3e7, 1e300, np.inf, np.nan], dtype=np.float64)
     with np.errstate(all="ignore"):
