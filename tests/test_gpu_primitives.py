@@ -76,7 +76,15 @@ def test_compact_sincos_within_one_ulp_of_glibc(krlib):
     for op, f in ((4, np.sin), (5, np.cos)):
         u = ulps(probe(op, x), f(x))
         assert u.max() <= 1.0, (op, u.max())
-        assert (u == 0).mean() > 0.997          # correctly rounded on the device: what differs is where the host libm is not (measured 99.8-99.99 %)
+    # correctly rounded on the device: against glibc itself (what the reference calls; numpy may use a vector library) it differs only where
+    # glibc is not (measured 99.8-99.99 % bit-equal)
+    libm = C.CDLL("libm.so.6")
+    xs = x[:300_000]
+    for op, name in ((4, "sin"), (5, "cos")):
+        f = getattr(libm, name)
+        f.restype, f.argtypes = C.c_double, [C.c_double]
+        want = np.array([f(v) for v in xs])
+        assert (probe(op, xs) == want).mean() > 0.997, name
     # far outside the polar-angle range and for non-finite input the library path answers
     big = np.array([1e5, -3e7, 1e300, np.inf, np.nan], dtype=np.float64)
     with np.errstate(all="ignore"):
