@@ -22,7 +22,7 @@ void ImagePlane<T>::init_image_plane(T D, T incl, T phi0, T x0, T xmax, T dx, T 
     Ray<T>* rays = Raytracer<T>::rays;
 
     // every pixel is a pure function of (i, j): columns are shared among the host threads
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(kr_host_threads())
     for (int i = 0; i < nx; i++) {
         const T x = x0 + i * dy;
         for (int j = 0; j < ny; j++) {

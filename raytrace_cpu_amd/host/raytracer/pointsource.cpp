@@ -20,7 +20,7 @@ void PointSource<T>::init_pointsource(T* pos, T dcosalpha, T dbeta, T cosalpha0,
     Ray<T>* rays = Raytracer<T>::rays;
     // every slot is a pure function of (i, j): rows are shared among the host threads (the reference's loop is serial;
     // at 1e7 rays it costs more than the whole GPU trace)
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(kr_host_threads())
     for (int i = 0; i < n_cosalpha; i++) {
         const T cosalpha = cosalpha0 + i * dcosalpha;
         for (int j = 0; j < n_beta; j++) {

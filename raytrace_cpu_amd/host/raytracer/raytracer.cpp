@@ -16,6 +16,8 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <typeinfo>
@@ -67,6 +69,46 @@ void no_outfile(const TextOutput* outfile)
                                  "it is an ordered per-step file write that the reference runs serially on the CPU");
 }
 
+// The HIP runtime takes ~0.13 s to come up in a fresh process.  It does so on a thread of its own, started by the first constructor, while
+// the constructing thread touches rays[] and the ray source fills it; whoever needs the device first (the first pass over an array) waits for
+// it and gives the array its device residency (kr_host_attach) then.
+struct DeviceWarmUp {
+    std::thread th;
+    std::mutex mu;
+    bool started = false;
+    std::map<const void*, std::pair<long, int>> pending;      // host arrays not attached yet: base -> (records, record bytes)
+    void start()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!started) { started = true; th = std::thread([] { (void) kr_device_count(); }); }
+    }
+    void announce(const void* rays, long n, int bytes)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (n > 0) pending[rays] = {n, bytes};
+    }
+    // before the first library call on `rays`
+    void ready(const void* rays)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (th.joinable()) th.join();
+        auto it = pending.find(rays);
+        if (it != pending.end()) {
+            (void) kr_host_attach(const_cast<void*>(rays), it->second.first, (int32_t) it->second.second);
+            pending.erase(it);
+            mark("attached (device buffer)");
+        }
+    }
+    // destructor of an array's owner: true if the array never reached the device
+    bool forget(const void* rays)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        return pending.erase(rays) > 0;
+    }
+    ~DeviceWarmUp() { if (th.joinable()) th.join(); }
+};
+DeviceWarmUp g_warm_up;
+
 }  // namespace
 
 template <typename T>
@@ -96,24 +138,21 @@ Raytracer<T>::Raytracer(int num_rays, T spin_par, T init_precision, T init_max_p
     if (bytes >= huge) (void) madvise(mem, ((bytes + huge - 1) / huge) * huge, MADV_HUGEPAGE);
 #endif
     rays = static_cast<Ray<T>*>(mem);
-    // the HIP runtime takes ~0.15 s to come up in a fresh process: let it do so on a thread of its own while this one touches rays[]
-    std::thread warm_up([] { (void) kr_device_count(); });
-#pragma omp parallel for schedule(static)
+    g_warm_up.start();                  // the HIP runtime comes up beside the first touch and the source constructor
+#pragma omp parallel for schedule(static) num_threads(kr_host_threads())
     for (int ray = 0; ray < nRays; ray++) {
         std::memset(static_cast<void*>(&rays[ray]), 0, sizeof(Ray<T>));
         rays[ray].steps = -1;
     }
-    warm_up.join();
     mark("Raytracer ctor: rays[] allocated and first touched");
-    if (nRays > 0) (void) kr_host_attach(rays, nRays, (int32_t) sizeof(Ray<T>));
-    mark("Raytracer ctor: attached (device buffer)");
+    g_warm_up.announce(rays, nRays, (int) sizeof(Ray<T>));      // device residency is set up by the first pass (DeviceWarmUp::ready)
 }
 
 template <typename T>
 Raytracer<T>::~Raytracer()
 {
     mark("Raytracer dtor: begin");
-    (void) kr_host_detach(rays);
+    if (!g_warm_up.forget(rays)) (void) kr_host_detach(rays);
     std::free(static_cast<void*>(rays));
     mark("Raytracer dtor: end");
 }
@@ -157,6 +196,7 @@ template <typename T>
 void Raytracer<T>::trace(const void* params, Ray<T>* first, long n)
 {
     if (n > 1) mark("run_raytrace: begin");
+    g_warm_up.ready(rays);
     check(trace_call(static_cast<const kr_params*>(params), first, n), "kr_trace");
     if (n > 1) mark("run_raytrace: end");
 }
@@ -352,6 +392,7 @@ template <typename T>
 void Raytracer<T>::redshift_start(T V, bool reverse, bool projradius)
 {
     mark("redshift_start: begin");
+    g_warm_up.ready(rays);
     check(PassOf<T>::type::redshift_start(spin, V, reverse, projradius, as_kr<T>(rays), nRays), "kr_redshift_start");
     mark("redshift_start: end");
 }
@@ -360,6 +401,7 @@ template <typename T>
 void Raytracer<T>::redshift(T V, bool reverse, bool projradius, int motion)
 {
     mark("redshift: begin");
+    g_warm_up.ready(rays);
     check(PassOf<T>::type::redshift(spin, V, reverse, projradius, motion, as_kr<T>(rays), nRays), "kr_redshift");
     mark("redshift: end");
 }
@@ -372,6 +414,7 @@ void Raytracer<T>::redshift(RayDestination<T>* dest, bool reverse, bool projradi
     double sp[4];
     bool default_velocity = false;
     if (builtin_destination(dest, kind, sp, default_velocity) && default_velocity) {
+        g_warm_up.ready(rays);
         check(PassOf<T>::type::redshift_dest(spin, reverse, as_kr<T>(rays), nRays), "kr_redshift_dest");
         return;
     }
@@ -388,6 +431,7 @@ template <typename T>
 void Raytracer<T>::range_phi(T min, T max)
 {
     mark("range_phi: begin");
+    g_warm_up.ready(rays);
     check(PassOf<T>::type::range_phi(min, max, as_kr<T>(rays), nRays), "kr_range_phi");
     mark("range_phi: end");
 }
@@ -395,6 +439,7 @@ void Raytracer<T>::range_phi(T min, T max)
 template <typename T>
 void Raytracer<T>::calculate_momentum()
 {
+    g_warm_up.ready(rays);
     check(PassOf<T>::type::calculate_momentum(spin, as_kr<T>(rays), nRays), "kr_calculate_momentum");
 }
 

@@ -31,11 +31,34 @@
 #define COUNT_MIN 100           // unused (kept for source compatibility)
 
 #include <cmath>
+#include <cstdlib>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <iomanip>
 #include <iostream>
 using namespace std;   // the reference header does this and its applications rely on it
 
 #include "../include/kerr.h"
+
+// Team size of the mirror's own host loops (first touch of rays[], the source constructors).  At most 32 threads, whatever the machine has:
+// these loops are memory-bound and done in 5-20 ms on 16-32 threads, while on a 256-thread box libgomp's idle workers keep spinning after each
+// region and starve the HIP runtime's own threads -- measured on the reference's emissivity main() at 1e7 rays: 1487 ms with 256 threads,
+// 1134 ms with 32 (scripts/app_threads.sh).  KRTRACE_HOST_THREADS overrides.
+inline int kr_host_threads()
+{
+#ifdef _OPENMP
+    static const int n = [] {
+        const char* e = std::getenv("KRTRACE_HOST_THREADS");
+        const int want = e ? std::atoi(e) : 32;
+        const int have = omp_get_max_threads();
+        return want > 0 ? (want < have ? want : have) : have;
+    }();
+    return n;
+#else
+    return 1;
+#endif
+}
 
 class TextOutput;      // only ever passed as a (null) pointer here; applications include text_output.h themselves
 
