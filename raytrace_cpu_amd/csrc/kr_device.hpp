@@ -116,17 +116,33 @@ KR_DEV float kr_sqrt(float x) { return __builtin_sqrtf(x); }
 #endif
 constexpr bool kRk45CrSincos = (KR_RK45_CR_SINCOS != 0);
 template <bool CR = true> KR_DEV void kr_sincos(double x, double& s, double& c) { kr_sincos_t<CR && (KR_CR_SINCOS != 0)>(x, s, c); }
-template <bool CR = true> KR_DEV void kr_sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+// float: evaluated in double and rounded once -- correctly rounded in all but ~1e-8 of the arguments, which is what glibc's sinf / cosf / powf / tanf
+// (the float instantiation's libm, <= 0.56 ulp) are in all but a few per cent: the float kernels then differ from the reference's float build only
+// where glibc's own float routines are not correctly rounded (the device library's float routines: <= 1-2 ulp).  KR_F32_VIA_F64=0: the device library.
+#ifndef KR_F32_VIA_F64
+#define KR_F32_VIA_F64 1
+#endif
+template <bool CR = true> KR_DEV void kr_sincos(float x, float& s, float& c)
+{
+#if KR_F32_VIA_F64
+    double sd, cd;
+    kr_sincos_fast_f64((double) x, sd, cd);
+    s = (float) sd;
+    c = (float) cd;
+#else
+    ::sincosf(x, &s, &c);
+#endif
+}
 // double: the strict path's own correctly rounded pair (kr_sincos.hpp) instead of the device libm (<= 1 ulp): the O(N) passes, the ray sources
 // and the FlatPlane stop test then differ from glibc only where glibc is not correctly rounded; the unused half is dead code
 KR_DEV double kr_sin(double x) { double s, c; kr_sincos_t<(KR_CR_SINCOS != 0)>(x, s, c); return s; }
-KR_DEV float kr_sin(float x) { return ::sinf(x); }
+KR_DEV float kr_sin(float x) { float s, c; kr_sincos<true>(x, s, c); return s; }
 KR_DEV double kr_cos(double x) { double s, c; kr_sincos_t<(KR_CR_SINCOS != 0)>(x, s, c); return c; }
-KR_DEV float kr_cos(float x) { return ::cosf(x); }
+KR_DEV float kr_cos(float x) { float s, c; kr_sincos<true>(x, s, c); return c; }
 KR_DEV double kr_tan(double x) { return ::tan(x); }
-KR_DEV float kr_tan(float x) { return ::tanf(x); }
+KR_DEV float kr_tan(float x) { return KR_F32_VIA_F64 ? (float) ::tan((double) x) : ::tanf(x); }
 KR_DEV double kr_pow(double x, double y) { return ::pow(x, y); }
-KR_DEV float kr_pow(float x, float y) { return ::powf(x, y); }
+KR_DEV float kr_pow(float x, float y) { return KR_F32_VIA_F64 ? (float) ::pow((double) x, (double) y) : ::powf(x, y); }
 
 // x^(1/5) for the DOPRI5 step controller (raytracer.cpp:1517: pow(1/max(err, 1e-10), 0.2), then 0.9 x that clamped to
 // [0.1, 5]).  The clamp makes the root matter only for x in [1.7e-5, 5.3e3]; x is first brought into [1e-6, 1e6], which
@@ -161,7 +177,7 @@ KR_DEV double fifth_root_for_controller(double x)
     return ::pow(x, 0.2);
 #endif
 }
-KR_DEV float fifth_root_for_controller(float x) { return ::powf(x, 0.2f); }
+KR_DEV float fifth_root_for_controller(float x) { return KR_F32_VIA_F64 ? (float) ::pow((double) x, (double) 0.2f) : ::powf(x, 0.2f); }
 KR_DEV double kr_log(double x) { return ::log(x); }
 KR_DEV double kr_acos(double x) { return ::acos(x); }
 KR_DEV double kr_asin(double x) { return ::asin(x); }
