@@ -189,6 +189,14 @@ void Raytracer<T>::fill_params(void* out, Integrator method, T r_max, int stepli
     p->integrator = static_cast<int>(method);   // Euler, RK4, RK45 == KR_EULER, KR_RK4, KR_RK45
     p->stop_kind = KR_STOP_THETA;
     p->steplim = steplim;                        // <= 0 selects STEPLIM / RK45_STEPLIM inside the library
+    // KRTRACE_STEPLIM=<n>: the limit used where the application passes none (the reference's STEPLIM is 1e7 for Euler / RK4).  A ray that runs
+    // to that limit -- a photon trapped between radial turning points inside the ISCO, which run_raytrace(RayDestination*) does not stop: 1 ray in
+    // 1e6 on two of thirteen test geometries -- is 1e7 SEQUENTIAL steps: ~1 s on a CPU core, ~15 s on a GPU wave, and the launch cannot end
+    // before it does.  Every consumer drops such rays (steps < 0); a lower limit only marks them STEPLIM sooner.
+    if (steplim <= 0) {
+        static const int env_steplim = [] { const char* e = std::getenv("KRTRACE_STEPLIM"); return e ? std::atoi(e) : 0; }();
+        if (env_steplim > 0 && (method != Integrator::RK45 || env_steplim < RK45_STEPLIM)) p->steplim = env_steplim;
+    }
     p->flags = arithmetic_flags(p->integrator);
 }
 

@@ -3,7 +3,8 @@
 For a set of sources (heights, spins, off-axis positions, orbiting sources, image planes at several inclinations) the compiled
 reference traces ~1e6 rays on the host cores and the HIP path traces the same initial rays in hybrid and in strict mode; per
 configuration: rays whose integer outcome (status, steps, flips, crossings) differs, rays beyond 1e-9, strict-side ray count.
-usage: python tests/tool_gpu_hybrid_sweep.py [rays=1e6] [rk4|rk45|euler]   -> one JSON line per configuration"""
+usage: python tests/tool_gpu_hybrid_sweep.py [rays=1e6] [rk4|rk45|euler] [theta|flatdisc|isco]   -> one JSON line per configuration
+(third argument: the stop surface -- the theta-limit overload, or run_raytrace(RayDestination*) with FlatDiscDestination / DiscWithISCODestination)"""
 import json, math, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -12,6 +13,7 @@ from raytrace_cpu_amd import api, capi
 
 rays_n = float(sys.argv[1]) if len(sys.argv) > 1 else 1e6
 METHOD = {"rk4": capi.RK4, "rk45": capi.RK45, "euler": capi.EULER}[sys.argv[2] if len(sys.argv) > 2 else "rk4"]
+STOP = sys.argv[3] if len(sys.argv) > 3 else "theta"
 d = 1.99 / (math.sqrt(rays_n) - 1.0)
 configs = []
 for spin, pos, V, tag in [(0.998, [0, 10, 1e-3, 1.5707], 0.0, "lamp h=10 (BASELINE)"), (0.998, [0, 3, 1e-3, 0.0], 0.0, "lamp h=3"),
@@ -38,6 +40,10 @@ for kind, tag, spec, spin, V in configs:
         src.lib.ref_redshift_start(src.h, 0.0, 1, 0)
         p = capi.default_params(-spin)
         p.integrator, p.r_max = METHOD, 11000.0
+    if STOP == "flatdisc":
+        p = capi.copy_params(p, stop_kind=capi.STOP_FLATDISC, stop_params=(math.pi / 2,))
+    elif STOP == "isco":
+        p = capi.copy_params(p, stop_kind=capi.STOP_DISC_ISCO, stop_params=(api.lib().kr_kerr_isco(spin, 1), 400.0 if kind == "ps" else 30.0, math.pi / 2))
     init = src.snapshot()
     t0 = time.perf_counter()
     src.run(p)
@@ -45,7 +51,7 @@ for kind, tag, spec, spin, V in configs:
     want = src.snapshot()
     src.close()
     valid = want["steps"] != -1
-    row = {"config": tag, "rays": int(valid.sum()), "cpu_s": round(cpu_s, 2)}
+    row = {"config": tag, "stop": STOP, "rays": int(valid.sum()), "cpu_s": round(cpu_s, 2)}
     modes = (("hybrid", capi.FLAG_HYBRID), ("strict", 0)) + ((("strict_iterate_all", capi.FLAG_RK45_ITERATE_ALL),) if METHOD == capi.RK45 else ())
     for mode, flags in modes:
         got, st = api.trace(capi.copy_params(p, flags=flags), init)
