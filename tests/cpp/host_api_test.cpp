@@ -21,10 +21,33 @@ public:
     T velocity(T r, T theta, T phi) const override { return T(0.5) / (T(0.998) + r * std::sqrt(r)); }   // half Keplerian
 };
 
-int main()
+int main(int argc, char** argv)
 {
     const double spin = 0.998;
     double pos[4] = {0.0, 10.0, 1e-3, 1.5707};
+
+    // `host_api_test steplim-env` with KRTRACE_STEPLIM=40 in the environment: the limit applies where the application passes none
+    // (Euler / RK4 default STEPLIM = 1e7), marks the unfinished rays RAY_STATUS_STEPLIM with a negated count, and leaves an explicit steplim alone
+    if (argc > 1 && std::string(argv[1]) == "steplim-env") {
+        PointSource<double> a(pos, 0.0, spin, TOL, 0.2, 0.2, -0.995, 0.995, -M_PI, M_PI);
+        PointSource<double> b(pos, 0.0, spin, TOL, 0.2, 0.2, -0.995, 0.995, -M_PI, M_PI);
+        a.run_raytrace(Integrator::RK4, M_PI_2, 1000.0, 0);                                   // no steplim passed -> the environment's 40
+        b.run_raytrace(Integrator::RK4, M_PI_2, 1000.0, 0, 0, 1, -1, -1, true, 100000);       // explicit -> untouched
+        int capped = 0, live = 0;
+        for (int i = 0; i < a.get_count(); i++) {
+            if (b.rays[i].steps == -1) continue;
+            ++live;
+            if (b.rays[i].steps > 40) {
+                ++capped;
+                CHECK(a.rays[i].steps == -40 && (a.rays[i].status & RAY_STATUS_STEPLIM), "ray %d: steps %d status %d under KRTRACE_STEPLIM=40", i, a.rays[i].steps, a.rays[i].status);
+            } else {
+                CHECK(a.rays[i].steps == b.rays[i].steps, "ray %d finished early but differs: %d vs %d", i, a.rays[i].steps, b.rays[i].steps);
+            }
+        }
+        CHECK(live > 100 && capped > 50, "too few rays: live %d capped %d", live, capped);
+        std::printf(failures ? "FAIL\n" : "PASS\n");
+        return failures ? 1 : 0;
+    }
 
     // 1. whole-array run_raytrace == per-ray propagate_rk4 (single-ray launches of the same kernel)
     {

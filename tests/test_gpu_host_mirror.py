@@ -15,3 +15,10 @@ def test_host_api_program():
     subprocess.check_call(["make", "-s", "-C", d])
     r = subprocess.run([os.path.join(d, "host_api_test")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_krtrace_steplim_environment_knob():
+    """KRTRACE_STEPLIM bounds the rays of an unchanged program where it passes no step limit itself ('one ray is one sequential chain')."""
+    d = os.path.join(gc.ROOT, "tests", "cpp")
+    r = subprocess.run([os.path.join(d, "host_api_test"), "steplim-env"], capture_output=True, text=True, timeout=600, env=dict(os.environ, KRTRACE_STEPLIM="40"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout[-3000:] + r.stderr[-1000:]
