@@ -422,6 +422,45 @@ def test_f32_passes_vs_reference_float(krlib, case_name, run):
     parity.record_margin("test_f32_passes_vs_reference_float", f"{case_name}-{run}", {"n_traced": int(live.sum()), "n_bad": 0, "frac_bad": 0.0, "worst_ok": None}, **margins)
 
 
+def test_f32_device_pointer_passes_equal_the_host_pointer_ones(krlib):
+    """kr_*_dev_f32 (device pointers + stream) against kr_*_f32 (host pointers): the same kernels, so the same bits in every record."""
+    lib, vp = krlib, C.c_void_p
+    g = np.load(gc.golden_path("f32_ps_h10"))
+    spin = CASES["ps_h10"]["runs"]["rk4"].spin
+    fin = g["final__rk4"]
+    n = len(fin)
+    want = fin.copy()
+    api.range_phi(want, float(np.float32(-np.pi)), float(np.float32(np.pi)))
+    api.redshift(spin, -1.0, 0, 0, want)
+    api.calculate_momentum(spin, want)
+    want_dest = want.copy()
+    api.redshift_dest(spin, 0, want_dest)
+    want_start = g["init"].copy()
+    want_start["emit"] = 0
+    api.redshift_start(spin, 0.0, 0, 0, want_start)
+    d = vp()
+    capi.check(lib, lib.kr_malloc(C.byref(d), n * 84), "malloc")
+    try:
+        got = fin.copy()
+        capi.check(lib, lib.kr_memcpy_h2d(d, got.ctypes.data_as(vp), n * 84), "h2d")
+        capi.check(lib, lib.kr_range_phi_dev_f32(float(np.float32(-np.pi)), float(np.float32(np.pi)), d, n, None), "range_phi")
+        capi.check(lib, lib.kr_redshift_dev_f32(spin, -1.0, 0, 0, 0, d, n, None), "redshift")
+        capi.check(lib, lib.kr_calculate_momentum_dev_f32(spin, d, n, None), "momentum")
+        capi.check(lib, lib.kr_memcpy_d2h(got.ctypes.data_as(vp), d, n * 84), "d2h")
+        assert got.tobytes() == want.tobytes()
+        capi.check(lib, lib.kr_redshift_dest_dev_f32(spin, 0, d, n, None), "redshift_dest")
+        capi.check(lib, lib.kr_memcpy_d2h(got.ctypes.data_as(vp), d, n * 84), "d2h")
+        assert got.tobytes() == want_dest.tobytes()
+        start = g["init"].copy()
+        start["emit"] = 0
+        capi.check(lib, lib.kr_memcpy_h2d(d, start.ctypes.data_as(vp), n * 84), "h2d")
+        capi.check(lib, lib.kr_redshift_start_dev_f32(spin, 0.0, 0, 0, d, n, None), "redshift_start")
+        capi.check(lib, lib.kr_memcpy_d2h(start.ctypes.data_as(vp), d, n * 84), "d2h")
+        assert start.tobytes() == want_start.tobytes()
+    finally:
+        lib.kr_free(d)
+
+
 def test_degenerate_denominators_match_oracle(krlib):
     """Schwarzschild (a = 0) with a source on the axis region: h is ~0 for every ray, so phidot ~ 0 and the step
     heuristic divides by it; and a ray record placed exactly ON the pole (sin(theta) = 0).  Where IEEE division gives
