@@ -46,8 +46,13 @@ constexpr int kBlock = 256;          // classification kernel
 #endif
 constexpr int kTraceBlock = KR_TRACE_BLOCK;
 constexpr int kWavesPerBlock = kTraceBlock / 64;
+// A wave goes back to the queue when at least this many of its lanes are free (or none holds a ray).  The refill / finish / store code runs with
+// only the free lanes active, ~500 vector instructions per visit -- as much as an RK4 step: visiting for every single finished lane cost the image
+// plane (1.25 lanes per visit) 11 % and the Euler launches 26 %; waiting for 4 leaves ~1.5 lanes of 64 idle on average.
+// Measured 1 -> 4 (8 is the same): image plane 170.4 -> 151.7 ms, Euler 1e7 rays 55.2 -> 40.8, returning radiation 318 -> 307, headline 81.8 -> 80.7,
+// RK45 412 -> 406 (profiles/r02_ab_experiments.txt).
 #ifndef KR_REFILL_MIN
-#define KR_REFILL_MIN 1
+#define KR_REFILL_MIN 4
 #endif
 #ifndef KR_LONG_RAY_PRIO
 #define KR_LONG_RAY_PRIO 1
