@@ -88,6 +88,15 @@ def trace_wait(ticket, want_stats=True):
     return st.as_dict() if st else None
 
 
+def trace_wait_many(tickets):
+    """kr_trace_wait_many: waits for and releases all tickets in one call; returns the summed counters (kernel_ms etc.: the largest)."""
+    count = len(tickets)
+    tt = (C.c_void_p * count)(*[t.value if isinstance(t, C.c_void_p) else t for t in tickets])
+    tot = Stats()
+    capi.check(lib(), lib().kr_trace_wait_many(count, tt, None, C.byref(tot)), "kr_trace_wait_many")
+    return tot.as_dict()
+
+
 def trace_release(ticket):
     capi.check(lib(), lib().kr_trace_release(ticket), "kr_trace_release")
 

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -120,6 +120,7 @@ PROTOTYPES = {
     "kr_trace_async_f32": (_int, [P(Params), _vp, _i64, _vp, P(_vp)]),
     "kr_trace_batch_async_f64": (_int, [_i32, P(P(Params)), P(_vp), P(_i64), P(_vp), P(_vp)]),
     "kr_trace_wait": (_int, [_vp, P(Stats)]),
+    "kr_trace_wait_many": (_int, [_i32, P(_vp), P(Stats), P(Stats)]),
     "kr_trace_release": (_int, [_vp]),
     "kr_redshift_start_f64": (_int, [_dbl, _dbl, _int, _int, _vp, _i64]),
     "kr_redshift_start_dev_f64": (_int, [_dbl, _dbl, _int, _int, _vp, _i64, _vp]),

@@ -327,6 +327,28 @@ int kr_trace_batch_async_f64(int32_t count, const kr_params* const* p, void* con
 
 int kr_trace_wait(void* ticket, kr_stats* stats) { return trace_wait(ticket, stats); }
 
+int kr_trace_wait_many(int32_t count, void* const* tickets, kr_stats* per_ticket, kr_stats* total)
+{
+    if (count < 0 || (count > 0 && !tickets)) { set_error("kr_trace_wait_many: null argument"); return KR_EINVAL; }
+    if (total) std::memset(total, 0, sizeof(*total));
+    int first_rc = KR_OK;
+    for (int32_t i = 0; i < count; i++) {
+        kr_stats st;
+        const int rc = trace_wait(tickets[i], (per_ticket || total) ? &st : nullptr);
+        if (rc != KR_OK) { if (first_rc == KR_OK) first_rc = rc; continue; }
+        if (per_ticket) per_ticket[i] = st;
+        if (total) {
+            total->rays_total += st.rays_total; total->rays_traced += st.rays_traced; total->steps_total += st.steps_total;
+            total->rk45_attempts += st.rk45_attempts; total->rk45_rejects += st.rk45_rejects; total->rays_strict_side += st.rays_strict_side;
+            total->rk45_stationary_steps += st.rk45_stationary_steps; total->rk45_extrapolated_steps += st.rk45_extrapolated_steps;
+            total->kernel_ms = std::max(total->kernel_ms, st.kernel_ms);
+            total->strict_side_ms = std::max(total->strict_side_ms, st.strict_side_ms);
+            total->main_ms = std::max(total->main_ms, st.main_ms);
+        }
+    }
+    return first_rc;
+}
+
 int kr_trace_release(void* ticket)
 {
     trace_release(ticket);

@@ -253,3 +253,35 @@ def test_two_host_threads_trace_at_the_same_time(krlib):
     for t in threads:
         t.join()
     assert errors == []
+
+
+def test_wait_many_sums_the_tickets_of_a_batch(krlib):
+    """kr_trace_wait_many: one call for all tickets of a batch; the summed counters equal the sums over single kr_trace_dev_f64 calls."""
+    lib = krlib
+    specs = [bench.make_spec(capi, 0.02), bench.make_spec(capi, 0.013), bench.make_spec(capi, 0.03)]
+    specs[1].pos[1] = 5.0
+    bufs = [DeviceRays(lib, s) for s in specs]
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, bench.R_MAX, capi.FLAG_HYBRID
+    try:
+        want = {"rays_total": 0, "rays_traced": 0, "steps_total": 0, "rays_strict_side": 0}
+        finals = []
+        for b in bufs:
+            b.init()
+            st = api.trace_dev(p, b.d.value, b.n)
+            finals.append(b.fetch())
+        for b in bufs:
+            b.init()
+        tickets = api.trace_batch_async([p] * 3, [b.d.value for b in bufs], [b.n for b in bufs], None)
+        single = [api.trace_dev(p, b.d.value, b.n) for b in []]          # (nothing: the batch owns the buffers now)
+        tot = api.trace_wait_many(tickets)
+        for b, f in zip(bufs, finals):
+            assert same_bits(b.fetch(), f)
+        # the batch splits every trace (strict side launch), a lone call below 2^18 rays does not: compare what does not depend on that
+        assert tot["rays_total"] == sum(b.n for b in bufs)
+        assert tot["rays_traced"] == sum(int((f["steps"] != -1).sum()) for f in finals)
+        assert tot["steps_total"] == sum(int(np.abs(f["steps"][f["steps"] != -1].astype(np.int64)).sum()) for f in finals)
+        assert tot["rays_strict_side"] > 0 and tot["kernel_ms"] > 0
+    finally:
+        for b in bufs:
+            b.free()
