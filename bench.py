@@ -360,7 +360,7 @@ class ReturnRadiationWorkload:
         self.result_words = 4 * self.nr
         self.describe = (f"disc->disc returning radiation: {self.nr} source radii r_isco..500 x ~{int(rays)} rays (beta in [0,pi)), {args.integrator.upper()}, "
                          f"r_max=1.1*r_esc, per-radius relaunch (BASELINE configs[4])")
-        self.pipeline = ("per radius: [pointsource_init+redshift_start]+trace+range_phi+return_classification; " +
+        self.pipeline = ("per radius: [pointsource_init+redshift_start]+trace+[range_phi+return_classification]; " +
                          (f"radii round-robin over {self.nstreams} stream(s), longest launches first, one counter read-back at the end" if self.nstreams else
                           "all radii resident, traced by ONE merged batch (one side launch + one main launch over all radii)"))
         self.sharding = f"radii cyclic over {world} rank(s), " + ("fixed set of radii (strong scaling)" if args.scaling == "strong" else "radii added with the rank count (weak scaling)")
@@ -395,11 +395,10 @@ class ReturnRadiationWorkload:
                 jj, tt = tickets[len(done)]
                 done.append((jj, self.api.trace_wait(tt)))
             tickets.append((j, self.api.trace_async(self.p, rays_k, n, stream=st_k)))
-            capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(rays_k), n, vp(st_k)), "range_phi")
             b = capi.ReturnBins()
             b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, r_s, 1.5707
             b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
-            capi.check(lib, lib.kr_reduce_return_dev_f64(C.byref(b), vp(rays_k), n, vp(d_res + 32 * ir), vp(st_k)), "reduce")
+            capi.check(lib, lib.kr_post_return_dev_f64(-math.pi, math.pi, C.byref(b), vp(rays_k), n, vp(d_res + 32 * ir), vp(st_k)), "range_phi+reduce (fused)")
         for s in self.streams:
             cur.wait_stream(s)                       # whatever follows on the caller's stream (the all-reduce) sees every radius
         t1.record(cur)
@@ -437,11 +436,10 @@ class ReturnRadiationWorkload:
         tickets = self.api.trace_batch_async([self.p] * len(self.specs), [b.data_ptr() for b in self.buffers], self.counts, [stream] * len(self.specs))
         for j, ((ir, r_s), s) in enumerate(zip(self.radii, self.specs)):
             rays_k, n = self.buffers[j].data_ptr(), self.counts[j]
-            capi.check(lib, lib.kr_range_phi_dev_f64(-math.pi, math.pi, vp(rays_k), n, vp(stream)), "range_phi")
             b = capi.ReturnBins()
             b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, r_s, 1.5707
             b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
-            capi.check(lib, lib.kr_reduce_return_dev_f64(C.byref(b), vp(rays_k), n, vp(d_res + 32 * ir), vp(stream)), "reduce")
+            capi.check(lib, lib.kr_post_return_dev_f64(-math.pi, math.pi, C.byref(b), vp(rays_k), n, vp(d_res + 32 * ir), vp(stream)), "range_phi+reduce (fused)")
         t1.record(cur)
         tot = self.api.trace_wait_many(tickets)          # one call for the hundred tickets: their counters summed
         t1.synchronize()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 9
+#define KR_ABI_VERSION 10
 
 /* error codes */
 #define KR_OK          0
@@ -335,6 +335,8 @@ int kr_reduce_image_dev_f64(const kr_image_bins* b, const void* d_rays, int64_t 
  * the app's three fractions are out[1..3] / out[0].  _dev ADDS into d_out4 (4 doubles, zero first). */
 int kr_reduce_return_f64(const kr_return_bins* b, const kr_ray_f64* rays, int64_t n, double out[4]);
 int kr_reduce_return_dev_f64(const kr_return_bins* b, const void* d_rays, int64_t n, void* d_out4, void* stream);
+/* range_phi(lo, hi) + kr_reduce_return_dev_f64 in one pass over the records (the returning-radiation driver's two passes after a trace) */
+int kr_post_return_dev_f64(double lo, double hi, const kr_return_bins* b, void* d_rays, int64_t n, void* d_out4, void* stream);
 
 /* ---- diagnostics ------------------------------------------------------------------------------- */
 /* out[i] = op(a[i], b[i]) evaluated ON THE DEVICE with the exact primitive the trace kernel uses (host pointers):

@@ -39,6 +39,7 @@ int post_image_dev(double spin, double V, int reverse, int projradius, int motio
 int pointsource_init_emit_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, double V, int reverse, int projradius, hipStream_t st);
 int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st);
 int reduce_return_dev(const kr_return_bins* b, const void* d, int64_t n, void* d_out4, hipStream_t st);
+int post_return_dev(double lo, double hi, const kr_return_bins* b, void* d, int64_t n, void* d_out4, hipStream_t st);
 int arith_probe_dev(int op, const double* a, const double* b, double* out, int64_t n);
 
 static thread_local std::string g_error;
@@ -637,6 +638,13 @@ int kr_reduce_return_dev_f64(const kr_return_bins* b, const void* d, int64_t n, 
     if (!b || !d_out4) { set_error("kr_reduce_return: null argument"); return KR_EINVAL; }
     int rc = require_device();
     return rc != KR_OK ? rc : reduce_return_dev(b, d, n, d_out4, (hipStream_t) st);
+}
+
+int kr_post_return_dev_f64(double lo, double hi, const kr_return_bins* b, void* d, int64_t n, void* d_out4, void* st)
+{
+    if (!b || !d_out4) { set_error("kr_post_return: null argument"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : post_return_dev(lo, hi, b, d, n, d_out4, (hipStream_t) st);
 }
 
 int kr_reduce_return_f64(const kr_return_bins* b, const kr_ray_f64* rays, int64_t n, double out[4])

@@ -539,12 +539,19 @@ post_image_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, doubl
 
 // ---- returning-radiation classification (disc_source_photonfrac_r.cpp:97-126) ------------------------------------
 // out4 = {ray_count, return, escape, lost}; per-wave shuffle reduction, one atomic per wave and word
+// FUSED: range_phi(lo, hi) first, in the same pass over the records (kr_post_return_dev_f64)
+template <bool FUSED>
 __global__ void __launch_bounds__(kBlock)
-reduce_return_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_return_bins b, double* __restrict__ out4)
+reduce_return_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_return_bins b, double* __restrict__ out4, double lo, double hi)
 {
     double acc[4] = {0, 0, 0, 0};
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
-        const kr_ray_f64* ray = &rays[i];
+        kr_ray_f64* ray = &rays[i];
+        double phi = ray->phi;
+        if (FUSED) {
+            const double wrapped = range_phi_value<double>(phi, ray->steps, lo, hi);
+            if (!(wrapped == phi) && wrapped == wrapped) { ray->phi = wrapped; phi = wrapped; }
+        }
         if (!(ray->steps > 0)) continue;
         const double alpha = kr_acos(ray->alpha);          // rays[].alpha holds cos(alpha)
         const double sasb = kr_abs(kr_sin(alpha) * kr_sin(ray->beta));
@@ -553,7 +560,7 @@ reduce_return_kernel(const kr_ray_f64* __restrict__ rays, long long n, kr_return
         acc[0] += b.weight_norm ? w : 1;
         const double r = ray->r;
         if (ray->theta >= kPi2 && r >= b.r_isco && r < b.r_disc) {
-            if (kr_abs(r - b.source_r) > 0.1 * b.source_r || kr_abs(ray->phi - b.source_phi) > 0.1) acc[1] += w;
+            if (kr_abs(r - b.source_r) > 0.1 * b.source_r || kr_abs(phi - b.source_phi) > 0.1) acc[1] += w;
         } else if (r > b.r_esc) {
             acc[2] += w;
         } else if (r < b.r_isco) {
@@ -742,7 +749,15 @@ int post_emissivity_dev(double spin, double V, int reverse, int projradius, int 
 int reduce_return_dev(const kr_return_bins* b, const void* d, int64_t n, void* d_out4, hipStream_t st)
 {
     if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(reduce_return_kernel, dim3(grid_for(n, 256 * 4)), dim3(kBlock), 0, st, (const kr_ray_f64*) d, (long long) n, *b, (double*) d_out4);
+    hipLaunchKernelGGL(reduce_return_kernel<false>, dim3(grid_for(n, 256 * 4)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *b, (double*) d_out4, 0.0, 0.0);
+    KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int post_return_dev(double lo, double hi, const kr_return_bins* b, void* d, int64_t n, void* d_out4, hipStream_t st)
+{
+    if (n <= 0) return KR_OK;
+    hipLaunchKernelGGL(reduce_return_kernel<true>, dim3(grid_for(n, 256 * 4)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *b, (double*) d_out4, lo, hi);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }

@@ -707,3 +707,39 @@ def test_fused_init_with_keplerian_V_on_a_shard_equals_the_unsharded_source(krli
         assert live.sum() > 100 and np.isfinite(shard["emit"][live]).all() and np.ptp(shard["emit"][live]) > 0
     finally:
         lib.kr_free(d)
+
+
+def test_fused_return_post_pass_equals_the_separate_passes(krlib):
+    """kr_post_return_dev_f64 == kr_range_phi_dev_f64 + kr_reduce_return_dev_f64: records bit-identical, the four sums equal to the order of the atomics."""
+    lib, vp = krlib, C.c_void_p
+    g = np.load(gc.golden_path("ps_h5"))
+    fin = g["final__rk4"].copy()
+    fin["phi"] += 40.0                          # so that range_phi has something to wrap
+    n = len(fin)
+    b = capi.ReturnBins()
+    b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = lib.kr_kerr_isco(gc.SPIN, 1), 400.0, 1000.0, 5.0, 0.0
+    b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 1, 1, 0
+    res = []
+    for fused in (False, True):
+        d, d_out = vp(), vp()
+        capi.check(lib, lib.kr_malloc(C.byref(d), n * 144), "malloc")
+        capi.check(lib, lib.kr_malloc(C.byref(d_out), 32), "malloc")
+        capi.check(lib, lib.kr_memset(d_out, 0, 32), "memset")
+        capi.check(lib, lib.kr_memcpy_h2d(d, fin.ctypes.data_as(vp), n * 144), "h2d")
+        if fused:
+            capi.check(lib, lib.kr_post_return_dev_f64(-np.pi, np.pi, C.byref(b), d, n, d_out, None), "post")
+        else:
+            capi.check(lib, lib.kr_range_phi_dev_f64(-np.pi, np.pi, d, n, None), "range_phi")
+            capi.check(lib, lib.kr_reduce_return_dev_f64(C.byref(b), d, n, d_out, None), "reduce")
+        rays, out = np.zeros(n, dtype=capi.RAY_F64), np.zeros(4)
+        capi.check(lib, lib.kr_memcpy_d2h(rays.ctypes.data_as(vp), d, n * 144), "d2h")
+        capi.check(lib, lib.kr_memcpy_d2h(out.ctypes.data_as(vp), d_out, 32), "d2h")
+        lib.kr_free(d)
+        lib.kr_free(d_out)
+        res.append((rays, out))
+    (r0, o0), (r1, o1) = res
+    assert ol.rays_equal_bitwise(r0, r1) == []
+    moved = r1["steps"] > 0
+    assert (r1["phi"][moved] != fin["phi"][moved]).mean() > 0.9          # range_phi did wrap (rays beyond |phi| = 1000 and NaN stay as they are)
+    assert o0[0] > 100 and o0[1] > 0 and o0[2] > 0
+    np.testing.assert_allclose(o1, o0, rtol=1e-12)
