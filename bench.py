@@ -11,7 +11,9 @@ rank r owns rows r, r+N, r+2N, ... (row-cyclic: neighbouring rows cost the same,
 i.e. per-GPU work is fixed (weak scaling); the only exchange is the all-reduce of the 5*Nr+1 histogram words.
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--integrator rk4|rk45|euler]
-        (N > 1: launched by torch.distributed.run, one rank per GPU)
+        N > 1 without RANK / WORLD_SIZE in the environment: bench.py starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+        itself, as a CHILD process (one rank per GPU over RCCL), relays rank 0's JSON line and exits with the child's code; it touches no GPU
+        itself.  Under torch.distributed.run (the driver's multi-GPU command) it is a rank.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -36,6 +38,36 @@ NR, R_DISC, GAMMA = 100, 500.0, 2.0             # emissivity.cpp defaults (Nr = 
 FLOP_PER_STEP = {"euler": 100.0, "rk4": 340.0, "rk45": 590.0}   # algorithmic fp64 FLOP per step / per RK45 attempt
 FP64_VECTOR_PEAK_TFLOPS = 78.6                   # MI355X vector fp64: 256 CU x 4 SIMD x 16 FMA lanes x 2 x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
+
+
+def self_launch_argv(argv, gpus, port, python=None):
+    """The command a rank-less `bench.py --gpus N` (N > 1) starts as a child: torch.distributed.run, one rank per GPU, rendezvous on
+    127.0.0.1 (the container's hostname may not resolve), the same bench arguments."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.join(ROOT, "bench.py"), *argv]
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(argv, gpus):
+    """Runs before anything touches the GPU (no torch import, no HIP call in this process): the reference's parallel loop needs no
+    launcher (raytracer.cpp:104), so neither does `bench.py --gpus N`.  Relays the child's stdout -- rank 0's ONE JSON line -- and its
+    stderr as they come; returns the child's exit code."""
+    import subprocess
+    cmd = self_launch_argv(argv, gpus, free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL across processes needs it)
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
 
 
 def make_spec(capi, d, rank=0, world=1, refine=1, strong=False):
@@ -479,6 +511,9 @@ def main():
     ap.add_argument("--cpu-sample-rays", type=float, default=0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))     # (nothing above or in there initialises the GPU)
+
     import torch
     from raytrace_cpu_amd import api, capi
 
@@ -486,10 +521,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (or leave RANK / WORLD_SIZE unset and bench.py starts them)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but this node shows {torch.cuda.device_count()} device(s)")
     torch.cuda.set_device(local_rank)
     lib = api.lib()
     capi.check(lib, lib.kr_set_device(local_rank), "kr_set_device")
@@ -612,7 +648,7 @@ def main():
                 traffic = None
         out = {
             "metric": "rays_per_sec", "value": traced_all * args.steps / elapsed, "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl.describe, "rays_per_gpu": int(traced), "allocated_rays_per_gpu": int(n), "rays_total": int(traced_all),
                        "integrator": args.integrator, "arithmetic": ARITHMETIC_NOTE[args.arithmetic], "rays_on_strict_side_launch": int(stats_last.get("rays_strict_side", 0)), "pipeline": wl.pipeline + (("+rccl_" + (getattr(wl, "exchange", "allreduce")) + ("(beside the next pass)" if overlap else "")) if dist is not None else ""),
