@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 10
+#define KR_ABI_VERSION 11
 
 /* error codes */
 #define KR_OK          0
@@ -74,8 +74,11 @@ extern "C" {
                                            (their outcome in the reference is decided by rounding) and NaN rays are integrated on
                                            the strict path, in a side launch whose waves own their SIMDs; all other rays take the
                                            fast-math path.  Reproduces the reference on every ray class at ~1.4x the strict speed.
-                                           The call synchronises `stream` once (an 8-byte read-back sizes the side launch) and
-                                           uses a second, internal stream of its own priority level for the concurrent launch.
+                                           Nothing in the call waits for the device: the number of flagged rays stays in device
+                                           memory, where the launches read it.  The concurrent launch runs on a second, internal
+                                           stream of its own priority level that belongs to `stream` (released by kr_stream_destroy /
+                                           kr_shutdown).  Growing the per-ray selector of a pooled workspace allocates (hipMalloc,
+                                           which does not synchronise); nothing is freed in the launch path.
                                            Ignored by the f32 entry points and when KR_FLAG_FAST_MATH is set. */
 #define KR_FLAG_RK45_ITERATE_ALL (1 << 2) /* RK45: iterate creeping captured rays to the step limit one step at a time, as the reference does,
                                            instead of extrapolating them (kr_stats.rk45_extrapolated_steps) */
@@ -366,7 +369,17 @@ int kr_synchronize(void* stream);
 /* streams for such callers (hipStreamCreateWithFlags(hipStreamNonBlocking) / hipStreamDestroy); the handle is what the *_dev
  * entry points take as `stream` */
 int kr_stream_create(void** stream);
-int kr_stream_destroy(void* stream);
+int kr_stream_destroy(void* stream);                /* also releases the internal side stream split traces on `stream` used */
+/* Hardware queues.  Traces are meant to overlap (a split trace uses two streams, a multi-launch driver keeps many in flight) and the
+ * HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues per device -- 4 by default: 18 concurrent RK45 sweep points take
+ * 1.65 s on 4 queues, 0.76 s on 16 (profiles/r02_hw_queues.txt).  The variable is read when the runtime initialises, and it is
+ * process-global: the library does NOT touch it.  An application that owns its process calls kr_configure_process() FIRST (before any
+ * other HIP user -- this library, PyTorch, RCCL -- starts the runtime); it sets GPU_MAX_HW_QUEUES=16 unless the user chose a value and
+ * returns 1, or returns 0 and changes nothing when the runtime is already up.  (bench.py, the kr_* apps and the class mirror call it.) */
+int kr_configure_process(void);
+/* Waits for the devices the library has used, then releases every pooled trace workspace and internal stream (outstanding tickets
+ * become invalid).  Optional, and never done implicitly: at process exit the HIP runtime may already be gone when this library is unloaded. */
+int kr_shutdown(void);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ using krapp::AxisInfo;
 
 int main(int argc, char** argv)
 try {
+    (void) kr_configure_process();       // first HIP user of this process: hardware queues for overlapping launches (include/kr_trace.h)
     ParameterArgs args(argc, argv);
     const string par_name = args.key_exists("--parfile") ? args.get_string_parameter("--parfile") : string("../par/imageplane_disc_image.par");
     ParameterFile par(par_name);

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -173,6 +173,8 @@ PROTOTYPES = {
     "kr_synchronize": (_int, [_vp]),
     "kr_stream_create": (_int, [P(_vp)]),
     "kr_stream_destroy": (_int, [_vp]),
+    "kr_configure_process": (_int, []),
+    "kr_shutdown": (_int, []),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libkrtrace.so")

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -44,15 +46,10 @@ int arith_probe_dev(int op, const double* a, const double* b, double* out, int64
 
 static thread_local std::string g_error;
 
-// Traces are meant to overlap (per-call workspaces, kr_trace_batch_async_f64): each one uses two streams, and a multi-launch driver
-// keeps many in flight.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues per device -- 4 by default -- and a
-// queue runs its kernels in order, so with more streams than queues a 0.4-s side launch holds up whatever else landed behind it:
-// 18 concurrent RK45 sweep points take 1.65 s on 4 queues, 0.99 s on 8, 0.76 s on 16, 0.67 s on 32 (profiles/r02_hw_queues.txt).
-// The variable is read when the runtime initialises, so it is set when this library is loaded, unless the user has chosen a value.
-__attribute__((constructor)) static void more_hardware_queues()
-{
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
-}
+// (hardware queues: include/kr_trace.h, kr_configure_process -- the library no longer edits the environment when it is loaded)
+static std::atomic<bool> g_runtime_touched{false};     // any entry point that reaches the HIP runtime sets it
+// (Nothing is released from a library destructor: at process exit the HIP runtime's own exit handlers may already have run -- they are
+// registered when the runtime starts, i.e. after this library's -- and calling into a torn-down runtime can hang.  kr_shutdown() is explicit.)
 
 void set_error(const std::string& msg) { g_error = msg; }
 
@@ -67,6 +64,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line)
 
 int require_device()
 {
+    g_runtime_touched = true;
     int n = 0;
     const hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -211,6 +209,7 @@ const char* kr_last_error(void) { return g_error.c_str(); }
 int kr_device_count(void)
 {
     int n = 0;
+    g_runtime_touched = true;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         (void) hipGetLastError();
         set_error("no HIP device available");
@@ -778,8 +777,22 @@ int kr_stream_create(void** stream)
 }
 int kr_stream_destroy(void* stream)
 {
-    if (stream) KR_HIP(hipStreamDestroy((hipStream_t) stream));
+    if (!stream) return KR_OK;
+    KR_HIP(hipStreamSynchronize((hipStream_t) stream));
+    side_stream_forget((hipStream_t) stream);
+    KR_HIP(hipStreamDestroy((hipStream_t) stream));
     return KR_OK;
+}
+int kr_configure_process(void)
+{
+    if (g_runtime_touched) return 0;
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    return 1;
+}
+int kr_shutdown(void)
+{
+    if (!g_runtime_touched) return KR_OK;
+    return trace_shutdown();
 }
 
 }  // extern "C"

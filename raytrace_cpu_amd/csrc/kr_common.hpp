@@ -34,5 +34,7 @@ int trace_async(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream,
 int trace_batch_async(int count, const kr_params* const* p, void* const* d_rays, const int64_t* n, void* const* streams, void** tickets);
 int trace_wait(void* ticket, kr_stats* stats);
 void trace_release(void* ticket);
+void side_stream_forget(hipStream_t user);
+int trace_shutdown();
 
 }  // namespace kr

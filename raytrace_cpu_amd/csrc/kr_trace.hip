@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -394,6 +395,7 @@ struct Workspace {
     int* list = nullptr;                         // device: kListCap ray indices
     unsigned char* mask = nullptr;               // device: one byte per ray
     int64_t mask_capacity = 0;
+    std::vector<void*> retired;                  // outgrown masks (workspace_mask_reserve)
     hipStream_t side_stream = nullptr;                   // the second stream of a split trace: belongs to the caller's stream (side_stream_for)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;             // the whole trace, caller's stream
     hipEvent_t ev_strict0 = nullptr, ev_strict1 = nullptr; // strict side (+ overflow) launch, caller's stream
@@ -420,16 +422,20 @@ constexpr int kMaxMultiGrid = 32768;                     // single-wave workgrou
 // It must not share a hardware queue with the caller's stream, or the two launches of a split serialise (seen once a process also
 // holds RCCL's streams: HIP multiplexes streams onto a few queues per priority level).  A different priority level has queues of
 // its own; the main launch it carries is also the one that may wait.
-std::map<std::pair<int, hipStream_t>, hipStream_t> g_side_streams;
+// One table per device, at most kMaxSideStreams entries each; a process that keeps making streams shares THAT DEVICE's side streams
+// (chosen by a hash of the caller's stream), and kr_stream_destroy / side_stream_forget drops an entry together with its side stream.
+constexpr size_t kMaxSideStreams = 16;
+std::map<hipStream_t, hipStream_t> g_side_streams[64];
 
 int side_stream_for(int dev, hipStream_t user, hipStream_t* out)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_side_streams.find({dev, user});
-    if (it == g_side_streams.end()) {
-        if (g_side_streams.size() >= 64) {                 // a process that keeps making streams: share what exists
-            it = g_side_streams.begin();
-            std::advance(it, (size_t) (((uintptr_t) user) >> 8) % g_side_streams.size());
+    auto& table = g_side_streams[dev];
+    auto it = table.find(user);
+    if (it == table.end()) {
+        if (table.size() >= kMaxSideStreams) {             // share one of this device's
+            it = table.begin();
+            std::advance(it, (size_t) (((uintptr_t) user) >> 8) % table.size());
             *out = it->second;
             return KR_OK;
         }
@@ -439,17 +445,32 @@ int side_stream_for(int dev, hipStream_t user, hipStream_t* out)
         if (const char* e = getenv("KR_SIDE_STREAM_PRIORITY")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "default") ? 0 : least;
         hipStream_t s = nullptr;
         KR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
-        it = g_side_streams.emplace(std::make_pair(dev, user), s).first;
+        it = table.emplace(user, s).first;
     }
     *out = it->second;
     return KR_OK;
+}
+
+void workspace_destroy(Workspace* w)
+{
+    if (!w) return;
+    if (w->counters) (void) hipFree(w->counters);
+    if (w->h_counters) (void) hipHostFree(w->h_counters);
+    if (w->list) (void) hipFree(w->list);
+    if (w->mask) (void) hipFree(w->mask);
+    if (w->d_descs) (void) hipFree(w->d_descs);
+    if (w->h_descs) (void) hipHostFree(w->h_descs);
+    for (void* old : w->retired) (void) hipFree(old);
+    for (hipEvent_t e : {w->ev0, w->ev1, w->ev_strict0, w->ev_strict1, w->ev_main0, w->ev_main1, w->ev_classified, w->done, w->ev_in})
+        if (e) (void) hipEventDestroy(e);
+    delete w;
 }
 
 int workspace_create(int dev, Workspace** out)
 {
     Workspace* w = new Workspace();
     w->device = dev;
-    auto fail = [&](int rc) { delete w; return rc; };       // (a half-built workspace leaks its few handles: only on a failing device)
+    auto fail = [&](int rc) { workspace_destroy(w); return rc; };
 #define KR_WS(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(kr::hip_fail(e__, #call, __FILE__, __LINE__)); } while (0)
     KR_WS(hipMalloc((void**) &w->counters, kCounterBlocks * kCounters * sizeof(unsigned long long)));
     KR_WS(hipHostMalloc((void**) &w->h_counters, kCounterBlocks * kCounters * sizeof(unsigned long long), hipHostMallocDefault));
@@ -468,6 +489,22 @@ int workspace_create(int dev, Workspace** out)
 #undef KR_WS
     w->cus = prop.multiProcessorCount;
     *out = w;
+    return KR_OK;
+}
+
+// The per-ray launch selector of a split trace grows geometrically and never frees in the launch path: hipFree synchronises the whole
+// device, i.e. every trace in flight on every stream would stall whenever a pooled workspace met a larger n (the returning-radiation
+// radii differ in ray count).  The outgrown buffer is parked on the workspace and released by kr_shutdown; the parked
+// bytes of a workspace sum to less than its current capacity.
+int workspace_mask_reserve(Workspace* ws, int64_t n)
+{
+    if (ws->mask_capacity >= n) return KR_OK;
+    const int64_t want = std::max<int64_t>(n, ws->mask_capacity + ws->mask_capacity / 2);
+    unsigned char* grown = nullptr;
+    KR_HIP(hipMalloc((void**) &grown, (size_t) want));
+    if (ws->mask) ws->retired.push_back(ws->mask);
+    ws->mask = grown;
+    ws->mask_capacity = want;
     return KR_OK;
 }
 
@@ -559,13 +596,14 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     constexpr int kRefill = KR_REFILL_MIN;
     auto kern = trace_kernel<T, METHOD, USE_DEST, FAST, HOG, kRefill>;
     // occupancy of each instance is a property of the code object: asked once per process
-    static int occ = 0;
-    if (occ == 0) {
+    static std::atomic<int> occ{0};                 // (host threads may race here: both would store the same value)
+    int blocks_per_cu = occ.load(std::memory_order_relaxed);
+    if (blocks_per_cu == 0) {
         int v = 0;
         KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, kTraceBlock, 0));
-        occ = v < 1 ? 1 : v;
+        blocks_per_cu = v < 1 ? 1 : v;
+        occ.store(blocks_per_cu, std::memory_order_relaxed);
     }
-    int blocks_per_cu = occ;
     // Resident workgroups per CU (= waves per SIMD).  The launch ends with its longest ray, which advances one step
     // per turn of its wave: with w waves per SIMD that turn comes round ~w times slower, while throughput keeps
     // improving up to ~3 waves.  Measured on MI355X, RK4 f64 strict, kernel ms at 1 / 2 / 3 workgroups per CU:
@@ -644,13 +682,9 @@ int launch_multi_f64(int integrator, bool dest, const TraceDesc<double>* d, int 
 int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream)
 {
     if (n > 0x7fffffff) { set_error("kr_trace: the split path indexes rays with 32 bits"); return KR_EINVAL; }
-    if (ws->mask_capacity < n) {
-        // (the workspace is idle: its previous call has completed, or it would not have been handed out)
-        if (ws->mask) KR_HIP(hipFree(ws->mask));
-        ws->mask = nullptr;
-        ws->mask_capacity = 0;
-        KR_HIP(hipMalloc((void**) &ws->mask, (size_t) n));
-        ws->mask_capacity = n;
+    {
+        const int rc = workspace_mask_reserve(ws, n);
+        if (rc != KR_OK) return rc;
     }
     unsigned long long* split_words = ws->counters + 3 * kCounters;     // [1] n_strict (zeroed by the caller's memset)
     const TraceConsts<double> c = make_consts<double>(p, steplim);
@@ -807,15 +841,18 @@ int trace_back(Pending& t)
     return KR_OK;
 }
 
-// after a failure part-way: whatever was enqueued must drain before the workspace is reused
+// After a failure part-way: whatever was enqueued must drain before the workspace is reused.  The kernels of a split trace sit on the
+// caller's stream AND its side stream, those of a merged batch on the batch's primary stream whatever t.stream is -- an event on
+// t.stream alone would not cover them -- so the (rare) error path simply waits for the device before it lets the workspace go.
 void abandon(Pending& t)
 {
     if (!t.ws) return;
+    (void) hipDeviceSynchronize();
+    (void) hipGetLastError();
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        t.ws->pending = true;
+        t.ws->pending = false;
     }
-    (void) hipEventRecord(t.ws->done, t.stream);
     workspace_release(t.ws);
     t.ws = nullptr;
 }
@@ -889,13 +926,8 @@ int merged_batch(std::vector<Pending>& ts, bool hybrid)
         Workspace* ws = t.ws;
         ws->side_stream = side;
         if (t.n > 0x7fffffff) { set_error("kr_trace: the split path indexes rays with 32 bits"); return KR_EINVAL; }
-        if (ws->mask_capacity < t.n) {
-            if (ws->mask) KR_HIP(hipFree(ws->mask));
-            ws->mask = nullptr;
-            ws->mask_capacity = 0;
-            KR_HIP(hipMalloc((void**) &ws->mask, (size_t) t.n));
-            ws->mask_capacity = t.n;
-        }
+        rc = workspace_mask_reserve(ws, t.n);
+        if (rc != KR_OK) return rc;
         KR_HIP(hipMemsetAsync(ws->counters, 0, kCounterBlocks * kCounters * sizeof(unsigned long long), primary));
         KR_HIP(hipEventRecord(ws->ev0, primary));
         unsigned long long* split_words = ws->counters + 3 * kCounters;
@@ -1050,6 +1082,50 @@ int trace_wait(void* ticket, kr_stats* stats)
 void trace_release(void* ticket)
 {
     if (ticket) workspace_release((Workspace*) ticket);
+}
+
+// kr_stream_destroy: the side stream that belonged to `user` goes with it (its work has drained: the caller's stream waits for it at the
+// end of every split trace, and is synchronised here before it is destroyed).
+void side_stream_forget(hipStream_t user)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void) hipGetLastError(); return; }
+    hipStream_t side = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_side_streams[dev].find(user);
+        if (it == g_side_streams[dev].end()) return;
+        side = it->second;
+        g_side_streams[dev].erase(it);
+        // (a workspace still pointing at it belongs to a finished call on the stream being destroyed, or to a sharer -- see below)
+        for (auto& kv : g_side_streams[dev]) if (kv.second == side) return;
+    }
+    (void) hipStreamSynchronize(side);
+    (void) hipStreamDestroy(side);
+}
+
+// kr_shutdown: waits for the devices this library has used, then gives back every pooled workspace and side stream.  Tickets still
+// outstanding become invalid.
+int trace_shutdown()
+{
+    int keep = 0;
+    const bool have_dev = hipGetDevice(&keep) == hipSuccess;
+    (void) hipGetLastError();
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (int dev = 0; dev < 64; dev++) {
+        if (g_pool[dev].empty() && g_side_streams[dev].empty()) continue;
+        if (hipSetDevice(dev) != hipSuccess) { (void) hipGetLastError(); continue; }
+        (void) hipDeviceSynchronize();
+        for (Workspace* w : g_pool[dev]) workspace_destroy(w);
+        g_pool[dev].clear();
+        std::vector<hipStream_t> seen;
+        for (auto& kv : g_side_streams[dev])
+            if (std::find(seen.begin(), seen.end(), kv.second) == seen.end()) { seen.push_back(kv.second); (void) hipStreamDestroy(kv.second); }
+        g_side_streams[dev].clear();
+    }
+    if (have_dev) (void) hipSetDevice(keep);
+    (void) hipGetLastError();
+    return KR_OK;
 }
 
 int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, kr_stats* stats, bool f32)

@@ -80,23 +80,30 @@ struct DeviceWarmUp {
     void start()
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!started) { started = true; th = std::thread([] { (void) kr_device_count(); }); }
+        // (an unchanged reference program owns its process and this is its first HIP user: more hardware queues for overlapping launches,
+        // include/kr_trace.h::kr_configure_process -- a no-op when the user chose GPU_MAX_HW_QUEUES or the runtime is already up)
+        if (!started) { started = true; (void) kr_configure_process(); th = std::thread([] { (void) kr_device_count(); }); }
     }
     void announce(const void* rays, long n, int bytes)
     {
         std::lock_guard<std::mutex> lk(mu);
         if (n > 0) pending[rays] = {n, bytes};
     }
-    // before the first library call on `rays`
-    void ready(const void* rays)
+    // before the first library call on `rays`.  whole_array: the call is a pass over rays[] -- only then is the device residency worth
+    // n x 176 B on the device; a program that only ever calls propagate*() on single rays stages just those records.
+    void ready(const void* rays, bool whole_array = true)
     {
         std::lock_guard<std::mutex> lk(mu);
         if (th.joinable()) th.join();
+        if (!whole_array) return;
         auto it = pending.find(rays);
         if (it != pending.end()) {
-            (void) kr_host_attach(const_cast<void*>(rays), it->second.first, (int32_t) it->second.second);
+            const int rc = kr_host_attach(const_cast<void*>(rays), it->second.first, (int32_t) it->second.second);
             pending.erase(it);
-            mark("attached (device buffer)");
+            if (rc != KR_OK)      // not fatal: every pass then stages through a private buffer (slower); say so once
+                std::fprintf(stderr, "raytrace_cpu_amd: no device residency for rays[] (%s); passes will stage through temporary buffers\n", kr_last_error());
+            else
+                mark("attached (device buffer)");
         }
     }
     // destructor of an array's owner: true if the array never reached the device
@@ -158,13 +165,19 @@ Raytracer<T>::~Raytracer()
 }
 
 // Arithmetic of the double-precision trace (include/kr_trace.h), chosen by the environment so that
-// the reference's applications need no new option: KRTRACE_ARITHMETIC = hybrid | strict | fast.  Unset: hybrid for the
-// fixed-step integrators, strict for RK45 -- the adaptive step control amplifies the few-ulp differences of the fast
-// arithmetic into +-1 differences of the step counts, and an RK45 launch is bounded by its longest ray either way.
-static int arithmetic_flags(int integrator)
+// the reference's applications need no new option: KRTRACE_ARITHMETIC = hybrid | strict | fast.  Unset:
+//   * theta-limit overloads, Euler / RK4: hybrid;  RK45: strict -- the adaptive step control amplifies the few-ulp differences of the
+//     fast arithmetic into +-1 differences of the step counts, and an RK45 launch is bounded by its longest ray either way;
+//   * run_raytrace(RayDestination*), every integrator: STRICT.  A destination that does not stop rays at their first equatorial crossing
+//     (DiscWithISCO inside the ISCO / beyond r_out, FlatPlane) lets them whirl near the photon sphere and come back; at a <= 0.5 that is
+//     0.1-0.35 % of a lamp post's rays, and the reference's own result for them is decided at the 1-ulp level (a 1-ulp change of Q on the
+//     CPU: 946 of 1e6 rays with another integer outcome, tests/tool_oracle_isco_noise.py).  Only the arithmetic that carries the
+//     reference's bits reproduces them (strict: 0 integer differences on 13 geometries x 1e6 rays, profiles/r03_hybrid_sweep_rk4_isco.jsonl);
+//     no in-flight criterion separates those rays from the 7-18 % that merely pass inside the ISCO.  Cost: 1.3-2.8 x the hybrid launch.
+static int arithmetic_flags(int integrator, bool destination)
 {
     const char* e = std::getenv("KRTRACE_ARITHMETIC");
-    if (!e || !*e) return integrator == KR_RK45 ? 0 : KR_FLAG_HYBRID;
+    if (!e || !*e) return (destination || integrator == KR_RK45) ? 0 : KR_FLAG_HYBRID;
     if (!std::strcmp(e, "hybrid")) return KR_FLAG_HYBRID;
     if (!std::strcmp(e, "strict")) return 0;
     if (!std::strcmp(e, "fast")) return KR_FLAG_FAST_MATH;
@@ -197,14 +210,14 @@ void Raytracer<T>::fill_params(void* out, Integrator method, T r_max, int stepli
         static const int env_steplim = [] { const char* e = std::getenv("KRTRACE_STEPLIM"); return e ? std::atoi(e) : 0; }();
         if (env_steplim > 0 && (method != Integrator::RK45 || env_steplim < RK45_STEPLIM)) p->steplim = env_steplim;
     }
-    p->flags = arithmetic_flags(p->integrator);
+    p->flags = arithmetic_flags(p->integrator, false);      // (the RayDestination overloads choose again once the destination is known)
 }
 
 template <typename T>
 void Raytracer<T>::trace(const void* params, Ray<T>* first, long n)
 {
     if (n > 1) mark("run_raytrace: begin");
-    g_warm_up.ready(rays);
+    g_warm_up.ready(rays, n > 1);
     check(trace_call(static_cast<const kr_params*>(params), first, n), "kr_trace");
     if (n > 1) mark("run_raytrace: end");
 }
@@ -235,6 +248,7 @@ void Raytracer<T>::run_raytrace(RayDestination<T>* dest, Integrator method, T r_
     if (!builtin_destination(dest, p.stop_kind, p.stop_params, default_velocity))
         throw std::runtime_error("Raytracer::run_raytrace: only FlatDiscDestination, DiscWithISCODestination and FlatPlaneDestination "
                                  "can be evaluated by the HIP kernel; a user-defined RayDestination would need per-step host callbacks");
+    p.flags = arithmetic_flags(p.integrator, true);
     trace(&p, rays, nRays);
 }
 
@@ -286,7 +300,8 @@ int Raytracer<T>::propagate_rk45(int ray, const T rlim, const T thetalim, const 
 
 #define KR_DEST_OR_THROW                                                                                 \
     bool dv = false;                                                                                     \
-    if (!builtin_destination(dest, p.stop_kind, p.stop_params, dv)) throw std::runtime_error("unsupported RayDestination subclass")
+    if (!builtin_destination(dest, p.stop_kind, p.stop_params, dv)) throw std::runtime_error("unsupported RayDestination subclass"); \
+    p.flags = arithmetic_flags(p.integrator, true)
 
 template <typename T>
 int Raytracer<T>::propagate_rk4(int ray, const T rlim, RayDestination<T>* dest, const int steplim, TextOutput* outfile, int write_step,

@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the configuration the profiles and DESIGN figures describe (include/kr_trace.h::kr_configure_process): read when the HIP runtime starts,
+# i.e. it must be in the environment before torch initialises below -- the library itself no longer sets it
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)

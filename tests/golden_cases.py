@@ -5,7 +5,8 @@ Grids follow the reference's own tests, coarsened so that 
 stay small:
   ps_h5    src/tests/emissivity_rk45_test.cpp:37-51 / integrator_perf_test.cpp:35-45 source (0,5,1e-3,0), V=0
   ps_h10   BASELINE.json configs[0..1]: par_example/emissivity.par_example source + --source_h=10
-  ps_kep   src/tests/raytrace_rk4_test.cpp:26-32 (Keplerian source, default angular limits)
+  ps_kep   src/tests/raytrace_rk4_test.cpp:26-32 (Keplerian source, default angular limits); ps_kep5k: the same on 5000 rays
+  ps_h5_a05, ps_h10_a0   lamp posts at a = 0.5 / a = 0 for the RayDestination overloads (raytracer.cpp:1036-1254, :1600-1894)
   ip15/16  par_example/imageplane_disc_image.par_example geometry on a 16x16 / 17x17 ray grid
            (the 17x17 grid contains the (0,0) pixel whose constants are NaN)
 """
@@ -24,10 +25,10 @@ SPIN = 0.998
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
-def _ps(pos, V, dc, db, full_range=True):
+def _ps(pos, V, dc, db, full_range=True, spin=SPIN):
     if full_range:
-        return ol.pointsource_spec(pos, V, SPIN, dc, db, cosalpha0=-0.995, cosalphamax=0.995, beta0=-np.pi, betamax=np.pi)
-    return ol.pointsource_spec(pos, V, SPIN, dc, db)
+        return ol.pointsource_spec(pos, V, spin, dc, db, cosalpha0=-0.995, cosalphamax=0.995, beta0=-np.pi, betamax=np.pi)
+    return ol.pointsource_spec(pos, V, spin, dc, db)
 
 
 def kep_velocity(r, a=SPIN):
@@ -35,8 +36,8 @@ def kep_velocity(r, a=SPIN):
     return 1.0 / (a + r ** 1.5)
 
 
-def r_isco():
-    return ol.oracle().kro_kerr_isco(SPIN, 1)
+def r_isco(spin=SPIN):
+    return ol.oracle().kro_kerr_isco(spin, 1)
 
 
 def _params(integrator, stop_kind=capi.STOP_THETA, stop_params=(), spin=SPIN, r_max=1000.0, rk45_tol=1e-8, steplim=-1):
@@ -73,6 +74,25 @@ def cases():
         source=_ps([0.0, 5.0, 1e-3, 0.0], kep_velocity(5.0), 0.2, 0.2, full_range=False),
         start=(kep_velocity(5.0), 0, 0), post=(-1.0, 0, 0),
         runs={"euler": _params(capi.EULER), "rk4": _params(capi.RK4)})
+    # the same Keplerian source on a 40 x 125 grid (5000 rays): on the 320-ray grid above the reference's own 1-ulp noise envelope is
+    # 3-4 % of the rays -- a coarse-grid artefact a test cannot tell from a regression
+    c["ps_kep5k"] = dict(
+        source=_ps([0.0, 5.0, 1e-3, 0.0], kep_velocity(5.0), 0.05, 0.05, full_range=False),
+        start=(kep_velocity(5.0), 0, 0), post=(-1.0, 0, 0),
+        runs={"euler": _params(capi.EULER), "rk4": _params(capi.RK4)})
+    # run_raytrace(RayDestination*) AWAY from a = 0.998 (VERDICT r02 missing #2): at a <= 0.5 the ISCO lies well outside the photon
+    # sphere, rays cross the equatorial plane inside it, whirl and come back -- the reference's result for those rays is decided at
+    # the 1-ulp level (tests/tool_oracle_isco_noise.py), so only an arithmetic that carries its bits reproduces their integer outputs
+    for name, spin, pos in (("ps_h5_a05", 0.5, [0.0, 5.0, 1e-3, 0.0]), ("ps_h10_a0", 0.0, [0.0, 10.0, 1e-3, 0.0])):
+        ri = r_isco(spin)
+        c[name] = dict(
+            source=_ps(pos, 0.0, 0.05, 0.1, spin=spin), start=(0.0, 0, 0), post=(-1.0, 0, 0),
+            runs={
+                "rk4_isco": _params(capi.RK4, capi.STOP_DISC_ISCO, (ri, 400.0, half_pi), spin=spin),
+                "rk4_flatdisc": _params(capi.RK4, capi.STOP_FLATDISC, (half_pi,), spin=spin),
+                "rk45_isco": _params(capi.RK45, capi.STOP_DISC_ISCO, (ri, 400.0, half_pi), spin=spin),
+                "rk45_flatdisc": _params(capi.RK45, capi.STOP_FLATDISC, (half_pi,), spin=spin),
+            })
     ip = dict(dist=10000.0, inc_deg=80.0, x0=-30.0, xmax=30.0, y0=-30.0, ymax=30.0, spin=SPIN)
     incl = 80.0 * np.pi / 180
     c["ip15"] = dict(

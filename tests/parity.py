@@ -60,6 +60,7 @@ def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False, steps_slack=2):
     bad |= live & (dsteps > steps_slack)
     bad |= live & (np.sign(got["steps"]) != np.sign(want["steps"]))
     worst = 0.0
+    worst_any = np.zeros(len(got))                  # per ray: its largest relative error over the compared float fields
     fields = FLOAT_FIELDS + (("redshift",) if check_redshift else ())
     sunk = (want["status"] & (capi.STATUS_HORIZON | capi.STATUS_STEPLIM)) != 0
     for f in fields:
@@ -74,6 +75,7 @@ def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False, steps_slack=2):
         err = np.where(np.isnan(err), np.inf, err)
         err = np.where((g == w), 0.0, err)          # equal infinities
         bad |= live & (err > rtol)
+        worst_any = np.maximum(worst_any, np.where(live, err, 0.0))
         ok = live & ~bad
         if ok.any():
             worst = max(worst, float(err[ok].max()))
@@ -86,7 +88,10 @@ def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False, steps_slack=2):
     bits = live & ~int_bad & (got["steps"] == want["steps"])
     for f in FLOAT_FIELDS:
         bits &= (got[f].view(np.int64) == want[f].view(np.int64)) | (np.isnan(got[f]) & np.isnan(want[f]))
-    return {"frac_bit_identical": float(bits.sum()) / max(n_live, 1), "n_traced": n_live, "n_bad": int(bad.sum()), "frac_bad": float(bad.sum()) / max(n_live, 1), "worst_ok": worst,
+    # how far out the rays beyond the bar are (finite errors only; a NaN / inf mismatch counts as inf), and which rays they are
+    wb = worst_any[bad]
+    worst_bad = float(wb.max()) if len(wb) else 0.0
+    return {"worst_bad": worst_bad, "median_bad": float(np.median(wb)) if len(wb) else 0.0, "frac_bit_identical": float(bits.sum()) / max(n_live, 1), "n_traced": n_live, "n_bad": int(bad.sum()), "frac_bad": float(bad.sum()) / max(n_live, 1), "worst_ok": worst,
             "n_steps_differ": int((live & (dsteps > 0)).sum()), "n_int_fields_differ": int(int_bad.sum()),
             "frac_terminal_status_differs": float(term_bad.sum()) / max(n_live, 1), "bad_index": np.flatnonzero(bad)}
 
@@ -156,6 +161,7 @@ _MARGINS = []
 
 def record_margin(test, case, res, allowed=None, envelope=None, **extra):
     row = {"test": test, "case": case, "n_traced": res["n_traced"], "n_bad": res["n_bad"], "frac_bad": res["frac_bad"], "worst_ok": res["worst_ok"],
+           "worst_bad": res.get("worst_bad"), "median_bad": res.get("median_bad"), "bad_index": [int(i) for i in res.get("bad_index", [])[:64]],
            "frac_bit_identical": res.get("frac_bit_identical"),
            "n_steps_differ": res.get("n_steps_differ"), "n_int_fields_differ": res.get("n_int_fields_differ"),
            "frac_terminal_status_differs": res.get("frac_terminal_status_differs"), "allowed_bad_frac": allowed, "noise_envelope_frac": envelope}

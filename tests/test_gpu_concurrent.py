@@ -285,3 +285,43 @@ def test_wait_many_sums_the_tickets_of_a_batch(krlib):
     finally:
         for b in bufs:
             b.free()
+
+
+def test_many_streams_share_side_streams_and_shutdown_releases_them(krlib):
+    """A process that makes one stream per job: beyond the per-device table of side streams (16) callers share this device's
+    side streams, kr_stream_destroy takes a stream's entry (and its side stream) with it, growing workspaces never free in the launch
+    path, and kr_shutdown gives everything back -- after which the library works as before.  Results: bit for bit the first trace's."""
+    lib = krlib
+    spec = bench.make_spec(capi, bench.grid_spacing_for(3.0e4))
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, bench.R_MAX, capi.FLAG_HYBRID
+    buf = DeviceRays(lib, spec)
+    big = DeviceRays(lib, bench.make_spec(capi, bench.grid_spacing_for(9.0e4)))      # a larger n on the same pooled workspaces: the mask grows
+    try:
+        buf.init()
+        want_st = api.trace_dev(p, buf.d.value, buf.n)
+        want = buf.fetch()
+        assert want_st["rays_strict_side"] > 0
+        streams = []
+        for k in range(40):
+            s = C.c_void_p()
+            capi.check(lib, lib.kr_stream_create(C.byref(s)), "stream")
+            streams.append(s)
+            buf.init(s.value)
+            st = api.trace_dev(p, buf.d.value, buf.n, stream=s.value)
+            assert st["steps_total"] == want_st["steps_total"]
+            assert same_bits(buf.fetch(), want), f"stream {k}"
+            if k % 3 == 2:                                   # some are destroyed on the way (their table entries go), most stay
+                capi.check(lib, lib.kr_stream_destroy(streams.pop(-2)), "destroy")
+        big.init(streams[0].value)
+        st_big = api.trace_dev(p, big.d.value, big.n, stream=streams[0].value)
+        assert st_big["rays_traced"] == int((big.fetch()["steps"] != -1).sum())
+        for s in streams:
+            capi.check(lib, lib.kr_stream_destroy(s), "destroy")
+        capi.check(lib, lib.kr_shutdown(), "kr_shutdown")
+        buf.init()
+        st = api.trace_dev(p, buf.d.value, buf.n)            # pools and side streams are rebuilt on demand
+        assert st["steps_total"] == want_st["steps_total"] and same_bits(buf.fetch(), want)
+    finally:
+        buf.free()
+        big.free()

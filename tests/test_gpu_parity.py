@@ -60,6 +60,10 @@ def test_trace_vs_golden(krlib, case_name, run, flags):
     parity.record_margin("test_trace_vs_golden", f"{case_name}-{run}-{mode}", res, allowed, envelope)
     assert res["n_traced"] > 0
     assert res["frac_bad"] <= allowed, res
+    if flags == 0 and params.integrator != capi.RK45 and params.stop_kind in (capi.STOP_FLATDISC, capi.STOP_DISC_ISCO) and not gc.is_imageplane(case):
+        # run_raytrace(RayDestination*) on the arithmetic the class mirror uses for it by default: the integer outcome of EVERY ray is the
+        # reference's -- at a = 0.998 and at a = 0 / 0.5, where 0.1-0.35 % of the rays are decided at the 1-ulp level (tests/tool_oracle_isco_noise.py)
+        assert res["n_int_fields_differ"] == 0 and res["n_steps_differ"] == 0, res
     if flags == 0 and params.integrator != capi.RK45:
         # strict arithmetic, fixed step: sin / cos are correctly rounded, everything else is IEEE -- nearly every ray carries the reference's bits in
         # every output (measured: PointSource 99.7-100 %, image plane 96.5-98.4 %: the rest is where glibc's own sin / cos is not correctly rounded)
@@ -79,7 +83,7 @@ def test_trace_vs_golden(krlib, case_name, run, flags):
 
 
 @pytest.mark.parametrize("flags", MODES)
-@pytest.mark.parametrize("case_name", ["ps_h5", "ps_h10", "ps_kep"])
+@pytest.mark.parametrize("case_name", ["ps_h5", "ps_h10", "ps_kep", "ps_kep5k"])
 @pytest.mark.parametrize("run", ["euler", "rk4", "rk45"])
 def test_emissivity_bins_vs_golden(krlib, case_name, run, flags):
     case = CASES[case_name]
