@@ -126,9 +126,23 @@ ARITHMETIC_NOTE = {
 }
 
 
+def omp_set_threads(n):
+    """The OpenMP runtime the CPU checkers run on (libgomp, shared by oracle/_ref and oracle/libkr_oracle.so): team size of the next parallel regions."""
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
 def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
-    """Times the CPU path on a bounded sample of the same workload (same source, same angular ranges, coarser
-    grid), on this box's host cores, and checks the GPU histogram of that same sample against it."""
+    """Times the CPU path on this box's host cores -- the reference's own run_raytrace (oracle/_ref) where it was built, else the oracle port --
+    and checks the GPU results ray by ray and bin by bin against it.  Two legs:
+      * thread sweep: the reference's `omp parallel for schedule(dynamic)` with an `omp atomic` progress counter (raytracer.cpp:104-124) does not
+        scale to every hardware thread of a 256-thread host, so a ~1e6-ray sample of the workload is timed at 64 / 128 / 256 threads (those the
+        box has) and the best team size is kept;
+      * the headline grid ITSELF (3162^2 rays, what `value` of the GPU line is quoted on) at that team size -- unless the sweep says it would take
+        more than ~90 s, or --cpu-sample-rays asks for a sample; the checks then run on the same rays the timing ran on."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol   # bench.py's cpu_baseline leg is one of the three places allowed to touch oracle/
     cores = os.cpu_count() or 1
@@ -136,28 +150,46 @@ def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    # ~ 2.5e4 rays per core: 10-30 s of CPU work at ~5e6 RK4 steps/s/core and ~550 steps/ray
-    sample_rays = int(args.cpu_sample_rays or 25000 * cores)
-    d = grid_spacing_for(sample_rays)
-    spec = make_spec(capi, d)
+    kind = "reference" if ol.ref() is not None else "port"
     p = capi.default_params(SPIN)
     p.integrator, p.r_max = integrator, R_MAX
-    kind = "reference" if ol.ref() is not None else "port"
-    if kind == "reference":
-        src = ol.RefSource(spec)                       # the reference's own PointSource<double>
-        src.lib.ref_redshift_start(src.h, 0.0, 0, 0)
-        init = src.snapshot()
-        t0 = time.perf_counter()
-        src.run(p)                                     # Raytracer::run_raytrace, OpenMP over all host cores
-        wall = time.perf_counter() - t0
-        cpu_rays = src.snapshot()
-        src.close()
-    else:
-        init = ol.oracle_pointsource(spec)
-        ol.oracle().kro_redshift_start_f64(SPIN, 0.0, 0, 0, ol.ptr(init), len(init))
-        t0 = time.perf_counter()
-        cpu_rays, _ = ol.oracle_trace(p, init, nthreads=cores)
-        wall = time.perf_counter() - t0
+
+    def run_cpu(d, threads):
+        spec = make_spec(capi, d)
+        omp_set_threads(threads)
+        if kind == "reference":
+            src = ol.RefSource(spec)                       # the reference's own PointSource<double>
+            src.lib.ref_redshift_start(src.h, 0.0, 0, 0)
+            init = src.snapshot()
+            t0 = time.perf_counter()
+            src.run(p)                                     # Raytracer::run_raytrace, OpenMP
+            wall = time.perf_counter() - t0
+            out = src.snapshot()
+            src.close()
+        else:
+            init = ol.oracle_pointsource(spec)
+            ol.oracle().kro_redshift_start_f64(SPIN, 0.0, 0, 0, ol.ptr(init), len(init))
+            t0 = time.perf_counter()
+            out, _ = ol.oracle_trace(p, init, nthreads=threads)
+            wall = time.perf_counter() - t0
+        return spec, init, out, wall
+
+    # leg 1: team size
+    sweep = {}
+    teams = sorted({t for t in (64, 128, 256) if t <= cores} | {cores}) if cores > 64 else [cores]
+    d_sweep = grid_spacing_for(min(1.0e6, 25000.0 * cores))
+    for t in teams:
+        _, _, out_t, wall_t = run_cpu(d_sweep, t)
+        live = out_t["steps"] != -1
+        sweep[t] = {"rays": int(live.sum()), "wall_s": wall_t, "rays_per_sec": int(live.sum()) / wall_t, "rays_per_sec_per_thread": int(live.sum()) / wall_t / t}
+    best = max(sweep, key=lambda t: sweep[t]["rays_per_sec"])
+    # leg 2: the headline grid itself (or a sample)
+    full_rays = (math.floor(1.99 / d_full) + 1) ** 2
+    est_full_s = full_rays / sweep[best]["rays_per_sec"]
+    on_headline_grid = not args.cpu_sample_rays and est_full_s <= 90.0
+    d = d_full if on_headline_grid else grid_spacing_for(args.cpu_sample_rays or 25000 * cores)
+    spec, init, cpu_rays, wall = run_cpu(d, best)
+    omp_set_threads(cores)
     valid = cpu_rays["steps"] != -1
     n_valid = int(valid.sum())
     steps = int(np.abs(cpu_rays["steps"][valid].astype(np.int64)).sum())
@@ -210,10 +242,13 @@ def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
     rays_check["strict_arithmetic_bit_identical_frac(t, r, theta, phi, redshift, integer fields)"] = float(bits[valid].mean())
     unit = "rays/s"
     return {
-        "value": n_valid / wall, "unit": unit, "cores": cores, "kind": kind,
-        "sample": f"same source and angular ranges on a {math.isqrt(len(init))}^2-ish grid: {n_valid} rays, {steps} steps, "
-                  f"run_raytrace only ({'reference sources, g++ -O2 -fopenmp -ffp-contract=off' if kind == 'reference' else 'oracle C port, gcc -O2 -fopenmp'})",
-        "steps_per_sec": steps / wall, "wall_s": wall,
+        "value": n_valid / wall, "unit": unit, "cores": best, "host_threads_available": cores, "kind": kind,
+        "sample": (f"the headline grid itself ({math.isqrt(len(init))}^2 grid points)" if on_headline_grid else
+                   f"same source and angular ranges on a {math.isqrt(len(init))}^2-ish grid") +
+                  f": {n_valid} rays, {steps} steps, run_raytrace only ({'reference sources, g++ -O2 -fopenmp -ffp-contract=off' if kind == 'reference' else 'oracle C port, gcc -O2 -fopenmp'}), "
+                  f"OpenMP team of {best} threads = the best of the sweep below",
+        "steps_per_sec": steps / wall, "wall_s": wall, "rays_per_sec_per_thread": n_valid / wall / best,
+        "thread_sweep": {"what": f"run_raytrace on a {sweep[best]['rays']}-ray sample of the same source at each team size", "teams": {str(t): v for t, v in sweep.items()}},
         "bins_check": {"bins": int(nr), "bins_count_mismatch": int((~same).sum()), "max_count_diff": int(np.abs(cnt - got["count"]).max()),
                        "max_rel_diff_on_matching_bins": worst, "tolerance": 1e-6},
         "rays_check": rays_check,
@@ -639,13 +674,17 @@ def main():
         units = (stats_last["rk45_attempts"] - stats_last["rk45_stationary_steps"] - stats_last["rk45_extrapolated_steps"]) if args.integrator == "rk45" else steps_total
         flop = FLOP_PER_STEP[args.integrator] * units                                            # this rank's launch
         achieved_tflops = flop / (avg_kernel_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes of the trace kernels per pass: PMC counters cannot be read from inside this process (rocprofv3 wraps it), so `traffic` is null
+        # on this line and the figure of the round's committed counter run rides along under its own name, with its source
+        traffic_from_profile = None
         tfile = os.path.join(ROOT, "profiles", "trace_kernel_hbm_traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(f"{args.workload}_{args.integrator}")
+                tj = json.load(open(tfile))
+                if f"{args.workload}_{args.integrator}" in tj:
+                    traffic_from_profile = {"bytes_per_pass": tj[f"{args.workload}_{args.integrator}"], "source": tj.get("_source", "profiles/trace_kernel_hbm_traffic.json")}
             except Exception:
-                traffic = None
+                traffic_from_profile = None
         out = {
             "metric": "rays_per_sec", "value": traced_all * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "rccl_ranks": (dist.get_world_size() if dist is not None else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -662,7 +701,7 @@ def main():
                          "split_launch_ms": {"strict_side": stats_last.get("strict_side_ms", 0.0), "main": stats_last.get("main_ms", 0.0)},
                          "hbm": {"algorithmic_bytes": 288 * int(traced), "achieved_gbs": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9,
                                  "peak_gbs": HBM_PEAK_GBS, "frac": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                         "traffic": traffic,
+                         "traffic": None, "traffic_from_profile": traffic_from_profile,
                          "note": "latency-bound scalar fp64 ODE: neither HBM nor MFMA bounds it (SURVEY.md 8d); priced against vector fp64 peak"},
         }
         out.update(wl.summary(h))

@@ -44,17 +44,31 @@ KR_DEV float kr_abs(float x) { return __builtin_fabsf(x); }
 // measured and rejected: a range test per quotient 231 ms, an out-of-line IEEE re-run per evaluation 227 ms, the
 // compiler's division 188 ms, unguarded lean chains 165 ms (PointSource 1e7 rays, RK4): every guard splits the
 // scheduling region the independent chains overlap in.  -DKR_LEAN_IEEE=0 builds the compiler's sequences throughout.
-KR_DEV double lean_div(double a, double b)
+// The reciprocal both forms below start from: v_rcp_f64 (~2^-23) and ONE cubic step, y0 (1 + e + e^2) = (1 / b)(1 - e^3) with e = 1 - b y0:
+// 2^-69 before its rounding, i.e. as close to RN(1 / b) as the two Newton steps of the compiler's sequence get (one fused operation
+// more), which is all the final correction q + (a - b q) y needs to land on the correctly rounded quotient (Markstein).  KR_LEAN_DIV_CUBIC=0:
+// the two Newton steps.
+#ifndef KR_LEAN_DIV_CUBIC
+#define KR_LEAN_DIV_CUBIC 1
+#endif
+KR_DEV double lean_recip(double b)
 {
-    double y = __builtin_amdgcn_rcp(b);
-    double e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    double q = a * y;
-    e = __builtin_fma(-b, q, a);
-    return __builtin_fma(e, y, q);
+    const double y0 = __builtin_amdgcn_rcp(b);
+    const double e = __builtin_fma(-b, y0, 1.0);
+#if KR_LEAN_DIV_CUBIC
+    return __builtin_fma(y0, __builtin_fma(e, e, e), y0);
+#else
+    const double y1 = __builtin_fma(y0, e, y0);
+    return __builtin_fma(y1, __builtin_fma(-b, y1, 1.0), y1);
+#endif
 }
+// a / b given y = lean_recip(b): several quotients over one denominator share the reciprocal (same bits as lean_div(a, b) each)
+KR_DEV double lean_div_y(double a, double b, double y)
+{
+    const double q = a * y;
+    return __builtin_fma(__builtin_fma(-b, q, a), y, q);
+}
+KR_DEV double lean_div(double a, double b) { return lean_div_y(a, b, lean_recip(b)); }
 
 // a / b for a divisor b that is uniform over the launch, given inv_b = RN(1/b) computed on the host in IEEE arithmetic.
 // q0 = RN(a inv_b) is within an ulp of a/b, r = a - b q0 is exact in the FMA, and RN(q0 + r inv_b) is then the correctly
@@ -90,6 +104,11 @@ template <bool LEAN> KR_DEV double dv(double a, double b) { if constexpr (LEAN) 
 template <bool LEAN> KR_DEV float dv(float a, float b) { return a / b; }
 template <bool LEAN> KR_DEV double sq(double x) { if constexpr (LEAN) return lean_sqrt(x); else return __builtin_sqrt(x); }
 template <bool LEAN> KR_DEV float sq(float x) { return __builtin_sqrtf(x); }
+// 1 / b for several quotients over b (lean: the refined reciprocal; otherwise unused) and the quotient that goes with it
+template <bool LEAN> KR_DEV double dv_recip(double b) { if constexpr (LEAN) return lean_recip(b); else return 0.0; }
+template <bool LEAN> KR_DEV float dv_recip(float) { return 0.0f; }
+template <bool LEAN> KR_DEV double dv_y(double a, double b, double y) { if constexpr (LEAN) return lean_div_y(a, b, y); else return a / b; }
+template <bool LEAN> KR_DEV float dv_y(float a, float b, float) { return a / b; }
 KR_DEV double div_const(double a, double b, double inv_b, bool ok)
 {
 #if KR_LEAN_IEEE
@@ -186,6 +205,10 @@ KR_DEV double kr_atan2(double y, double x) { return ::atan2(y, x); }
 template <typename T> KR_DEV T std_max(T a, T b) { return (a < b) ? b : a; }
 template <typename T> KR_DEV T std_min(T a, T b) { return (b < a) ? b : a; }
 
+// y + 2 x, rounded once: the product is exact, so this IS the two-operation sum the reference writes (bit for bit), in one instruction
+KR_DEV double kr_fma2(double x, double y) { return __builtin_fma(2.0, x, y); }
+KR_DEV float kr_fma2(float x, float y) { return __builtin_fmaf(2.0f, x, y); }
+
 template <typename T> struct Lim;
 template <> struct Lim<double> { static KR_DEV double max() { return 1.7976931348623157e308; } };
 template <> struct Lim<float> { static KR_DEV float max() { return 3.402823466e38f; } };
@@ -203,6 +226,17 @@ template <typename T> struct TraceConsts {
     bool rk45_extrapolate;                  // RK45: creeping captured rays are extrapolated to the step limit (default)
     int32_t steplim;
     int32_t stop_kind;
+    // The optional clauses of the step heuristic ("if (max_tstep > 0 && r < maxtstep_rlim) ...", "if (max_phistep > 0) ...", "if (rlim > 0 && ...)",
+    // "if (thetalim > 0 && ...)", raytracer.cpp:855-871) with the launch-uniform half folded into the constant the per-ray half compares against:
+    // a disabled clause gets the value that makes its own comparison false for every ray (r < -inf; step > |inf / phidot|; x > +inf).  Same
+    // decisions on every ray, and no uniform lane masks for the compiler to carry (and spill) through the step loop.
+    T tstep_rlim_eff;       // max_tstep > 0 ? maxtstep_rlim : -inf
+    T phistep_eff;          // max_phistep > 0 ? max_phistep : +inf
+    T rlim_clip;            // rlim > 0 ? rlim : +inf
+    T thetalim_clip;        // thetalim > 0 ? thetalim : +inf
+    // loop condition of the theta-limit overloads, (tl > 0 && theta < tl) || (tl < 0 && theta > |tl|) || tl == 0  (:799), as theta_lo < theta < theta_hi:
+    // tl > 0: (-inf, tl);  tl < 0: (|tl|, +inf);  tl == 0: (-inf, +inf);  NaN: empty (theta_hi = -inf)
+    T theta_lo, theta_hi;
 };
 
 // ---- per-lane ray state ---------------------------------------------------------------------
@@ -224,6 +258,9 @@ template <typename T> struct Lane {
     int32_t creep_run;      // ... and in this many consecutive outer steps before it
     bool creep_mode;        // the rest of the ray is replayed step by step from k1 alone (step_rk45)
     T creep_dt, creep_dphi; // its t and phi increments per step
+    // fast arithmetic, fixed-step integrators: sin / cos of theta carried from the previous step's base point by angle addition (step_fixed)
+    bool carry_ok;
+    T carry_sin, carry_cos;
     // RK45, strict arithmetic: what the accepted trial's last stage (k7) already knows about the point the next step's k1 is taken at
     bool fsal_valid;
     T f_sin2theta, f_rhosq, f_delta, f_pt, f_thetadotsq, f_abs_ptheta;
@@ -270,7 +307,7 @@ KR_DEV void momentum(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_s
 // bodies' association of the phidot denominator ((sin2theta*rhosq)*delta, :1375 vs :818).
 // Returns true when the reference would `continue` (theta turning point: sign flipped, nothing moves).
 template <typename T, bool RK45_ASSOC, bool LEAN>
-KR_DEV bool k1_impl(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
+KR_DEV bool k1_impl(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y_rhosq_o = nullptr)
 {
     const T r = s.r, theta = s.theta, k = s.k, h = s.h;
     T sin_theta, cos_theta;
@@ -303,7 +340,8 @@ KR_DEV bool k1_impl(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
     s.ptheta = sq<LEAN>(kr_abs(thetadotsq)) * s.thetadot_sign;
 
     T rdotsq = k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta;
-    rdotsq = dv<LEAN>(rdotsq * delta, rhosq);
+    const T y_rhosq = dv_recip<LEAN>(rhosq);          // (the caller's two flag quotients over rho^2 reuse it: step_fixed)
+    rdotsq = dv_y<LEAN>(rdotsq * delta, rhosq, y_rhosq);
     if (rdotsq <= 0 && s.r_was_positive) {
         s.rdot_sign = -s.rdot_sign;
         s.r_was_positive = false;
@@ -315,13 +353,14 @@ KR_DEV bool k1_impl(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
 
     rhosq_o = rhosq;
     sin2theta_o = sin2theta;
+    if (y_rhosq_o) *y_rhosq_o = y_rhosq;
     return false;
 }
 
 template <typename T, bool RK45_ASSOC>
-KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
+KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y_rhosq_o = nullptr)
 {
-    return k1_impl<T, RK45_ASSOC, LeanDefault<T>::value>(s, a, rhosq_o, sin2theta_o);
+    return k1_impl<T, RK45_ASSOC, LeanDefault<T>::value>(s, a, rhosq_o, sin2theta_o, y_rhosq_o);
 }
 
 // RK45: the k1 of a step that follows an ACCEPTED trial is taken at the point that trial's last stage (k7) was evaluated at, and most
@@ -369,13 +408,24 @@ KR_DEV bool k1_from_last_stage(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
 // v_rcp_f64 / v_rsq_f64 (<= ~1 ulp) and FMA contraction.  Results differ from the strict path by a few ulp per
 // operation -- the same order as the libm difference that already separates the strict path from the CPU -- and are
 // held to the same parity tolerances (tests/test_gpu_parity.py runs both).
+#ifndef KR_RCP_CUBIC
+#define KR_RCP_CUBIC 1
+#endif
 KR_DEV double fast_rcp(double x)
 {
+    // v_rcp_f64 is good to ~2^-23; with e = 1 - x y one CUBIC step y (1 + e + e^2) = (1/x)(1 - e^3) lands at 2^-69 before its own rounding
+    // (<= 1 ulp, tests/test_gpu_primitives.py) in three fused operations -- two Newton steps, the textbook route to the same accuracy, take four
+#if KR_RCP_CUBIC
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, y, 1.0);
+    const double p = __builtin_fma(e, e, e);
+    return __builtin_fma(y, p, y);
+#else
     double y = __builtin_amdgcn_rcp(x);
-
     y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
     y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
     return y;
+#endif
 }
 
 // One Newton step (relative error ~2^-46): for the step-size heuristic only, whose quotients end up under min() / as a step length
@@ -394,74 +444,93 @@ KR_DEV double fast_rcp_heur(double x)
 }
 KR_DEV float fast_rcp_heur(float x) { return fast_rcp(x); }
 
-KR_DEV double fast_sqrt(double x)      // sqrt(max(|x|, 1e-300)): rsq seed + one coupled Newton step + a residual correction
+// max(|x|, 1e-300) as ONE v_max_f64 with the |.| source modifier.  (Left to the compiler, fmax(fabs(x), c) on a value that has been through
+// an integer operation or a select costs a v_and, a v_mov and a canonicalising v_max x, x first: four instructions, twice per k1.)
+KR_DEV double abs_floor(double x)
+{
+    double r;
+    asm("v_max_f64 %0, |%1|, %2" : "=v"(r) : "v"(x), "s"(1e-300));
+    return r;
+}
+
+// sqrt(max(|x|, 1e-300)): rsq seed + one coupled Newton step + a residual correction.  inv (optional): 1 / that root to ~2^-46 -- the seed
+// times (1 + e), with the e the root computes anyway: the step heuristic's 1 / |rdot| and 1 / |thetadot| for ONE more fused operation each
+// instead of a v_rcp_f64 (a quarter-rate instruction: 16 issue cycles against 4) and its Newton step.
+KR_DEV double fast_sqrt(double x, double* inv = nullptr)
 {
     // The floor replaces the x == 0 / x == inf special cases of a plain rsq-based root (5 instructions per call, 8 calls per
     // RK4 step) by one v_max: a vanishing theta-dot or r-dot becomes 1e-150 instead of 0, which no later operation can tell
     // apart (it is added to O(1) angles / radii, and its reciprocal only feeds step-size minima).  +inf gives NaN.
-    x = __builtin_fmax(__builtin_fabs(x), 1e-300);
+    x = abs_floor(x);
     const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
+    double g = x * y;
+    const double h = 0.5 * y;
     const double e = __builtin_fma(-h, g, 0.5);
+    if (inv) *inv = __builtin_fma(y, e, y);
     g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
+    // (the residual d is 2^-45 of x after the coupled step; the seed's h = 1 / (2 sqrt x) to 2^-23 scales it well enough -- the refined h
+    // of the textbook sequence would buy 2^-90 instead of 2^-68 before the final rounding, one instruction per root, eight roots per RK4 step)
     const double d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
 }
 
-struct FastAux { double rhosq, sin2theta, inv_rhosq, sn, cs; };
+struct FastAux { double sin2theta, inv_rhosq, sn, cs, inv_abs_pr, inv_abs_ptheta; };
 
-// momentum_from_consts (kerr.h:300-335) with a single reciprocal
-KR_DEV void momentum_fast_sc(double& pt, double& pr, double& ptheta, double& pphi, double k, double h, double Q, int rdot_sign,
-                             int thetadot_sign, double r, double s, double c, double a, FastAux* aux = nullptr,
-                             double* thetadotsq_o = nullptr, double* rdotsq_o = nullptr)
+// The four derivatives through the separated potentials (Carter): with P = (r^2 + a^2) k - a h,
+//   rho^2 tdot   = -a (a k sin^2 - h) + (r^2 + a^2) P / Delta        rho^4 thetadot^2 = Q + cos^2 (k^2 a^2 - h^2 / sin^2)  =: N
+//   rho^2 phidot = -(a k - h / sin^2) + a P / Delta                  rho^4 rdot^2     = P^2 - Delta (Q + (h - a k)^2) - Delta (|N| - N)  =: R
+// -- algebraically what kerr.h:300-335 evaluates (its rdot^2 = (k tdot - h phidot - rho^2 thetadot^2) Delta / rho^2 is the null condition
+// solved for rdot), and the radial equation does not wait for tdot and phidot.  (kerr.h:327-333 builds rdot^2 from |thetadot^2|: beyond a
+// polar turning point, where a Runge-Kutta stage may land, that differs from the analytic radial potential by 2 |thetadot^2| Delta -- the
+// last term of R: an O(step^3) kink the reference's solution contains, so it is kept.)  One reciprocal, 1 / (rho^2 Delta sin^2), from which
+// 1 / (rho^2 Delta), 1 / rho^2 and 1 / sin^2 follow by multiplication; the roots are taken of N and R and scaled by 1 / rho^2 afterwards.
+// Every fused multiply-add of the fast path is written out: with "#pragma clang fp contract(fast)" the compiler chose them per kernel
+// instance, and the same ray came out an ulp apart from the single-trace and the multi-trace kernels.
+struct FastPotentials { double N, R, inv_rho, s2, rhosq; };
+
+KR_DEV FastPotentials potentials_fast(double& pt, double& pphi, double k, double h, double Q, double r, double s, double c, double a)
 {
-    // (every fused multiply-add of the fast path is written out: with "#pragma clang fp contract(fast)" the compiler chose them per
-    // kernel instance, and the same ray came out an ulp apart from the single-trace and the multi-trace kernels)
     const double s2 = s * s;
     const double c2 = c * c;
     const double r2 = r * r;
     const double a2 = a * a;
+    const double r2a2 = r2 + a2;
     const double rhosq = __builtin_fma(a2, c2, r2);
-    const double delta = __builtin_fma(-2.0, r, r2) + a2;
+    const double delta = __builtin_fma(-2.0, r, r2a2);
     const double rd = rhosq * delta;
     const double inv = fast_rcp(rd * s2);          // 1 / (rho^2 Delta sin^2)
     const double inv_rd = inv * s2;                // 1 / (rho^2 Delta)
     const double inv_rho = inv_rd * delta;         // 1 / rho^2
     const double inv_s2 = inv * rd;                // 1 / sin^2
-
-    // The same four derivatives through the separated potentials (Carter): with P = (r^2 + a^2) k - a h,
-    //   rho^2 tdot   = -a (a k sin^2 - h) + (r^2 + a^2) P / Delta        rho^4 thetadot^2 = Q + cos^2 (k^2 a^2 - h^2 / sin^2)
-    //   rho^2 phidot = -(a k - h / sin^2) + a P / Delta                  rho^4 rdot^2     = P^2 - Delta (Q + (h - a k)^2)
-    // -- algebraically what kerr.h:300-335 evaluates (its rdot^2 = (k tdot - h phidot - rho^2 thetadot^2) Delta / rho^2 is the null
-    // condition solved for rdot), in 60 operations instead of 64, and the radial equation no longer waits for tdot and phidot.
-    const double ak = a * k, ah = a * h;                 // (loop-invariant per ray, like h^2, k^2 a^2 and the Carter term below)
-    const double P = __builtin_fma(r2 + a2, k, -ah);
-    pt = __builtin_fma(-(__builtin_fma(a * ak, s2, -ah)), inv_rho, ((r2 + a2) * P) * inv_rd);
+    const double ak = a * k, ah = a * h;           // (invariant along a ray, like h^2, k^2 a^2 and Q + (h - a k)^2 below: computed once per step)
+    const double P = __builtin_fma(r2a2, k, -ah);
+    pt = __builtin_fma(-(__builtin_fma(a * ak, s2, -ah)), inv_rho, (r2a2 * P) * inv_rd);
     pphi = __builtin_fma(__builtin_fma(h, inv_s2, -ak), inv_rho, (a * P) * inv_rd);
-
-    const double num = __builtin_fma(c2, __builtin_fma(-(h * h), inv_s2, ak * ak), Q);
-    const double inv_rho2 = inv_rho * inv_rho;
-    const double thsq = num * inv_rho2;
-    ptheta = fast_sqrt(__builtin_fabs(thsq)) * thetadot_sign;
-
-    // (kerr.h:327-333 builds rdot^2 from |thetadot^2|: beyond a polar turning point, where a Runge-Kutta stage may land, that differs
-    // from the analytic radial potential by 2 |thetadot^2| Delta -- an O(step^3) kink the reference's solution contains, so it is kept)
+    FastPotentials o;
+    o.N = __builtin_fma(c2, __builtin_fma(-(h * h), inv_s2, ak * ak), Q);
     const double hmak = h - ak;
-    const double rsq = __builtin_fma(-delta, __builtin_fabs(thsq) - thsq, __builtin_fma(-delta, __builtin_fma(hmak, hmak, Q), P * P) * inv_rho2);
-    pr = fast_sqrt(__builtin_fabs(rsq)) * rdot_sign;
-    if (aux) { aux->rhosq = rhosq; aux->sin2theta = s2; aux->inv_rhosq = inv_rho; }
-    if (thetadotsq_o) *thetadotsq_o = thsq;
-    if (rdotsq_o) *rdotsq_o = rsq;
+    o.R = __builtin_fma(-delta, __builtin_fabs(o.N) - o.N, __builtin_fma(-delta, __builtin_fma(hmak, hmak, Q), P * P));
+    o.inv_rho = inv_rho;
+    o.s2 = s2;
+    o.rhosq = rhosq;
+    return o;
+}
+
+// momentum_from_consts (kerr.h:300-335)
+KR_DEV void momentum_fast_sc(double& pt, double& pr, double& ptheta, double& pphi, double k, double h, double Q, int rdot_sign,
+                             int thetadot_sign, double r, double s, double c, double a)
+{
+    const FastPotentials o = potentials_fast(pt, pphi, k, h, Q, r, s, c, a);
+    ptheta = fast_sqrt(o.N) * (o.inv_rho * thetadot_sign);
+    pr = fast_sqrt(o.R) * (o.inv_rho * rdot_sign);
 }
 
 KR_DEV void momentum_fast(double& pt, double& pr, double& ptheta, double& pphi, double k, double h, double Q, int rdot_sign,
-                          int thetadot_sign, double r, double theta, double a, FastAux* aux = nullptr, double* thetadotsq_o = nullptr,
-                          double* rdotsq_o = nullptr)
+                          int thetadot_sign, double r, double theta, double a)
 {
     double s, c;
     kr_sincos_fast_f64(theta, s, c);
-    momentum_fast_sc(pt, pr, ptheta, pphi, k, h, Q, rdot_sign, thetadot_sign, r, s, c, a, aux, thetadotsq_o, rdotsq_o);
+    momentum_fast_sc(pt, pr, ptheta, pphi, k, h, Q, rdot_sign, thetadot_sign, r, s, c, a);
 }
 
 // sin/cos of theta0 + d from those of theta0 (the stages of one Runge-Kutta step sit within a few per cent of a radian of its
@@ -472,76 +541,88 @@ KR_DEV void momentum_fast(double& pt, double& pr, double& ptheta, double& pphi, 
 #ifndef KR_STAGE_SINCOS_NEAR
 #define KR_STAGE_SINCOS_NEAR 1
 #endif
+// Horner steps of sincos_near: the coefficient as a scalar-register operand (KR_NEAR_SGPR, default) or a vector register the compiler re-creates per step
+#ifndef KR_NEAR_SGPR
+#define KR_NEAR_SGPR 1
+#endif
+#if KR_NEAR_SGPR
+#define KR_NEAR_FMA(a, b, c) kr_fma3s((a), (b), (c))
+#else
+#define KR_NEAR_FMA(a, b, c) kr_fma3((a), (b), KR_K(c))
+#endif
+#ifndef KR_NEAR_LIMIT
+#define KR_NEAR_LIMIT 0.07
+#endif
 // largest |d| for which sincos_near() uses the angle addition from theta0 (computed once per step, shared by its stages)
 KR_DEV double sincos_near_limit(double theta0)
 {
-    return __builtin_fmin(0.125, 0.5 * __builtin_fmin(__builtin_fabs(theta0), __builtin_fabs(kPi - theta0)));
+    return __builtin_fmin(KR_NEAR_LIMIT, 0.5 * __builtin_fmin(__builtin_fabs(theta0), __builtin_fabs(kPi - theta0)));
 }
 
 KR_DEV void sincos_near(double s0, double c0, double d, double& s, double& c)   // valid for |d| <= sincos_near_limit(theta0)
 {
+    // |d| <= 0.07 (the step heuristic keeps a whole RK4 step within theta / 50 <= 0.063): sin d through d^9 (next term d^11 / 11! <= 5e-21),
+    // cos d - 1 through d^8 (next d^10 / 10! <= 8e-19 of a sum of magnitude ~1): one Horner step less on each side than the 1/8 version
     const double d2 = d * d;
-    double ps = KR_K(-1.0 / 39916800.0);
-    ps = kr_fma3(ps, d2, KR_K(1.0 / 362880.0));
-    ps = kr_fma3(ps, d2, KR_K(-1.0 / 5040.0));
-    ps = kr_fma3(ps, d2, KR_K(1.0 / 120.0));
-    ps = kr_fma3(ps, d2, KR_K(-1.0 / 6.0));
+    double ps = KR_NEAR_FMA(d2, 1.0 / 362880.0, -1.0 / 5040.0);
+    ps = KR_NEAR_FMA(ps, d2, 1.0 / 120.0);
+    ps = KR_NEAR_FMA(ps, d2, -1.0 / 6.0);
     const double sd = __builtin_fma(d * d2, ps, d);                 // sin d
-    double pc = KR_K(-1.0 / 3628800.0);
-    pc = kr_fma3(pc, d2, KR_K(1.0 / 40320.0));
-    pc = kr_fma3(pc, d2, KR_K(-1.0 / 720.0));
-    pc = kr_fma3(pc, d2, KR_K(1.0 / 24.0));
+    double pc = KR_NEAR_FMA(d2, 1.0 / 40320.0, -1.0 / 720.0);
+    pc = KR_NEAR_FMA(pc, d2, 1.0 / 24.0);
     pc = __builtin_fma(pc, d2, -0.5);
     const double cm = d2 * pc;                                       // cos d - 1
-    s = s0 + __builtin_fma(c0, sd, s0 * cm);
-    c = c0 + __builtin_fma(-s0, sd, c0 * cm);
+    s = __builtin_fma(c0, sd, __builtin_fma(s0, cm, s0));
+    c = __builtin_fma(-s0, sd, __builtin_fma(c0, cm, c0));
 }
 
 // k1 with the turning-point logic (see k1_with_flips) on the fast path
+#ifndef KR_CARRY_SINCOS
+#define KR_CARRY_SINCOS 0
+#endif
+template <bool CARRY = false>
 KR_DEV bool k1_with_flips_fast(Lane<double>& s, double a, FastAux& aux)
 {
-    const double r = s.r, theta = s.theta, k = s.k, h = s.h;
     double sn, c;
-    kr_sincos_fast_f64(theta, sn, c);   // (carrying sin/cos from step to step by angle addition was measured 6 % SLOWER)
-    const double s2 = sn * sn;
-    const double c2 = c * c;
-    const double r2 = r * r;
-    const double a2 = a * a;
-    const double rhosq = __builtin_fma(a2, c2, r2);
-    const double delta = __builtin_fma(-2.0, r, r2) + a2;
-    const double rd = rhosq * delta;
-    const double inv = fast_rcp(rd * s2);
-    const double inv_rd = inv * s2;
-    const double inv_rho = inv_rd * delta;
-    const double inv_s2 = inv * rd;
-
-    const double ak = a * k, ah = a * h;                 // see momentum_fast_sc
-    const double P = __builtin_fma(r2 + a2, k, -ah);
-    s.pt = __builtin_fma(-(__builtin_fma(a * ak, s2, -ah)), inv_rho, ((r2 + a2) * P) * inv_rd);
-    s.pphi = __builtin_fma(__builtin_fma(h, inv_s2, -ak), inv_rho, (a * P) * inv_rd);
-
-    const double num = __builtin_fma(c2, __builtin_fma(-(h * h), inv_s2, ak * ak), s.Q);
-    const double inv_rho2 = inv_rho * inv_rho;
-    const double thetadotsq = num * inv_rho2;
-    if (thetadotsq < 0 && s.theta_was_positive) {
+    if constexpr (CARRY && KR_CARRY_SINCOS) {
+        // sin / cos of the base point: what the previous step derived by angle addition from ITS base point (step_fixed), when every lane of the
+        // wave has such a pair; else the full routine, and each lane still takes its own carried pair where it has one (which pair a ray
+        // uses is a function of that ray's history alone -- never of its neighbours in the wave)
+        // (the base point of a fixed-step integrator lies in [0, pi] -- reflect_poles -- so the routine's core is called directly: its
+        // out-of-range fallback is an out-of-line call that takes the addresses of its results, and with those in scope the compiler kept
+        // sn / c in scratch memory on this path too)
+        if (__builtin_amdgcn_ballot_w64(!s.carry_ok) == 0) {
+            sn = s.carry_sin; c = s.carry_cos;
+        } else {
+            double sf, cf;
+            kr_sincos_fast_core_f64(s.theta, sf, cf);
+            sn = s.carry_ok ? s.carry_sin : sf;
+            c = s.carry_ok ? s.carry_cos : cf;
+        }
+    } else {
+        kr_sincos_fast_f64(s.theta, sn, c);
+    }
+    const FastPotentials o = potentials_fast(s.pt, s.pphi, s.k, s.h, s.Q, s.r, sn, c, a);
+    // thetadot^2 = N / rho^4 and rdot^2 = R / rho^4 have the signs of N and R
+    if (o.N < 0 && s.theta_was_positive) {
         s.thetadot_sign = -s.thetadot_sign;
         s.theta_was_positive = false;
         return true;
     }
-    if (thetadotsq >= 0) s.theta_was_positive = true;
-    s.ptheta = fast_sqrt(__builtin_fabs(thetadotsq)) * s.thetadot_sign;
-
-    const double hmak = h - ak;
-    const double rdotsq = __builtin_fma(-delta, __builtin_fabs(thetadotsq) - thetadotsq, __builtin_fma(-delta, __builtin_fma(hmak, hmak, s.Q), P * P) * inv_rho2);
-    if (rdotsq <= 0 && s.r_was_positive) {
+    if (o.N >= 0) s.theta_was_positive = true;
+    double inv_root;
+    s.ptheta = fast_sqrt(o.N, &inv_root) * (o.inv_rho * s.thetadot_sign);
+    aux.inv_abs_ptheta = inv_root * o.rhosq;                   // 1 / |thetadot| = rho^2 / sqrt |N|
+    if (o.R <= 0 && s.r_was_positive) {
         s.rdot_sign = -s.rdot_sign;
         s.r_was_positive = false;
         s.rdot_flips++;
-    } else if (rdotsq > 0) {
+    } else if (o.R > 0) {
         s.r_was_positive = true;
     }
-    s.pr = fast_sqrt(__builtin_fabs(rdotsq)) * s.rdot_sign;
-    aux.rhosq = rhosq; aux.sin2theta = s2; aux.inv_rhosq = inv_rho; aux.sn = sn; aux.cs = c;
+    s.pr = fast_sqrt(o.R, &inv_root) * (o.inv_rho * s.rdot_sign);
+    aux.inv_abs_pr = inv_root * o.rhosq;
+    aux.sin2theta = o.s2; aux.inv_rhosq = o.inv_rho; aux.sn = sn; aux.cs = c;
     return false;
 }
 
@@ -560,8 +641,7 @@ KR_DEV bool loop_cond(const Lane<T>& s, const TraceConsts<T>& c)
 {
     bool ok = s.r < c.rlim && s.steps < c.steplim;
     if (!USE_DEST) {
-        const T tl = c.thetalim;
-        ok = ok && ((tl > 0 && s.theta < tl) || (tl < 0 && s.theta > kr_abs(tl)) || tl == 0);
+        ok = ok && s.theta < c.theta_hi && s.theta > c.theta_lo;        // (TraceConsts::theta_lo / theta_hi)
     }
     return ok;
 }
@@ -641,32 +721,55 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     T pt1, pr1, ptheta1, pphi1;
     FastAux aux;
     if constexpr (FAST) {
-        if (k1_with_flips_fast(s, a, aux)) return !(s.steps < c.steplim);
+        // (sin / cos carried from step to step: Euler only.  For RK4 it removes 7 of 406 vector instructions per step but costs registers
+        // the stage code needs -- 63.2 ms against 62.7 at 1e7 rays, profiles/r03_ab_experiments.txt)
+        if (k1_with_flips_fast<!RK4>(s, a, aux)) return !(s.steps < c.steplim);
         pt1 = s.pt; pr1 = s.pr; ptheta1 = s.ptheta; pphi1 = s.pphi;
-        // same heuristic, quotients as products with Newton-refined reciprocals
-        const T inv_pr = fast_rcp_heur(pr1), inv_pth = fast_rcp_heur(ptheta1);
-        const T q_th = kr_abs(s.theta * inv_pth);
-        step = kr_abs((s.r - c.horizon) * inv_pr) * c.inv_precision;
+        // The same heuristic (:855-871) with ONE quarter-rate instruction instead of four.  1 / |rdot| and 1 / |thetadot| come out of the
+        // square roots that produced them (fast_sqrt); the time and azimuth caps, min(dt / |tdot|, dphi / |phidot|), share one reciprocal:
+        // min(dt |phidot|, dphi |tdot|) / (|tdot| |phidot|).  A cap that is switched off is +inf in the numerator (TraceConsts), a NaN or 0 / 0
+        // quotient leaves the step as it is (v_min ignores a NaN operand) -- as the reference's "step > x" does.
+        const T inv_pr = aux.inv_abs_pr, inv_pth = aux.inv_abs_ptheta;          // magnitudes: every use below takes |.| anyway
+        const T q_th = kr_abs(s.theta) * inv_pth;
+        const T dr = s.r - c.horizon;
+        step = (kr_abs(dr) * inv_pr) * c.inv_precision;
         if (step > q_th * c.inv_precision) step = q_th * c.inv_theta_precision;
-        if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
-            const T st = kr_abs(c.max_tstep * fast_rcp_heur(pt1));
-            if (step > st) step = st;
+        {
+            const T apt = kr_abs(pt1), aphi = kr_abs(pphi1);
+            const T dt_eff = (s.r < c.tstep_rlim_eff) ? c.max_tstep : T(1e300);
+            const T num = __builtin_fmin(dt_eff * aphi, c.phistep_eff * apt);
+            step = __builtin_fmin(step, num * fast_rcp_heur(apt * aphi));
         }
-        if (c.max_phistep > 0) {
-            const T sp = kr_abs(c.max_phistep * fast_rcp_heur(pphi1));
-            if (step > sp) step = sp;
+        // "if (step < MIN_STEP) step = MIN_STEP" as v_max: differs from the comparison only when `step` is NaN, i.e. when r or rdot is -- and
+        // then r is NaN after this step whatever its length
+        step = __builtin_fmax(step, T(KR_MIN_STEP));
+        // the two landing clips apply on a ray's LAST step only: one fused test each, the clip itself behind a wave-uniform branch (the empty
+        // asm keeps the compiler from turning the branch back into unconditional arithmetic and selects)
+        {
+            const bool clip_r = __builtin_fma(pr1, step, s.r) > c.rlim_clip;
+            if (__builtin_amdgcn_ballot_w64(clip_r) != 0) {
+                asm volatile("" ::: "memory");
+                if (clip_r) step = kr_abs(c.rlim - s.r) * inv_pr;
+            }
         }
-        if (step < KR_MIN_STEP) step = KR_MIN_STEP;
-        if (c.rlim > 0 && s.r + pr1 * step > c.rlim) step = kr_abs((c.rlim - s.r) * inv_pr);
         if (!USE_DEST) {
-            if (c.thetalim > 0 && s.theta + ptheta1 * step > c.thetalim) step = kr_abs((c.thetalim - s.theta) * inv_pth);
+            const bool clip_th = __builtin_fma(ptheta1, step, s.theta) > c.thetalim_clip;
+            if (__builtin_amdgcn_ballot_w64(clip_th) != 0) {
+                asm volatile("" ::: "memory");
+                if (clip_th) step = kr_abs(c.thetalim - s.theta) * inv_pth;
+            }
         }
         if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
-        const T two_r_rho = 2 * s.r * aux.inv_rhosq;
-        if ((1 - two_r_rho) * pt1 + (two_r_rho * a * aux.sin2theta) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
+        // (1 - 2r/rho^2) tdot + (2 a r sin^2/rho^2) phidot IS the conserved energy k (= -p_t): analytically it cannot turn negative, and
+        // numerically only where its two terms (~ k / Delta) are 1e15 times k.  Away from the horizon, for k > 0, the test is skipped
+        // (wave-uniform; a NaN k or r takes the evaluation, whose comparison is then false as in the reference).
+        if (__builtin_amdgcn_ballot_w64(!(dr > T(1e-6)) || !(s.k > T(0))) != 0) {
+            const T two_r_rho = 2 * s.r * aux.inv_rhosq;
+            if ((1 - two_r_rho) * pt1 + (two_r_rho * a * aux.sin2theta) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
+        }
     } else {
-    T rhosq, sin2theta;
-    if (k1_with_flips<T, false>(s, a, rhosq, sin2theta)) return !(s.steps < c.steplim);   // r, theta unchanged
+    T rhosq, sin2theta, y_rhosq;
+    if (k1_with_flips<T, false>(s, a, rhosq, sin2theta, &y_rhosq)) return !(s.steps < c.steplim);   // r, theta unchanged
     pt1 = s.pt; pr1 = s.pr; ptheta1 = s.ptheta; pphi1 = s.pphi;
 
     // step-size heuristic (:224-243 / :855-871 / :1136-1151)
@@ -675,23 +778,29 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         const T q_th = kr_abs(dv<LeanDefault<T>::value>(s.theta, ptheta1));
         if (step > div_const(q_th, c.precision, c.inv_precision, c.inv_ok)) step = div_const(q_th, c.theta_precision, c.inv_theta_precision, c.inv_ok);
     }
-    if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
+    if (s.r < c.tstep_rlim_eff) {                       // max_tstep > 0 && r < maxtstep_rlim  (TraceConsts)
         const T st = kr_abs(dv<LeanDefault<T>::value>(c.max_tstep, pt1));
         if (step > st) step = st;
     }
-    if (c.max_phistep > 0) {
-        const T sp = kr_abs(dv<LeanDefault<T>::value>(c.max_phistep, pphi1));
+    {                                                   // max_phistep > 0: otherwise the quotient is inf / NaN and the comparison false
+        const T sp = kr_abs(dv<LeanDefault<T>::value>(c.phistep_eff, pphi1));
         if (step > sp) step = sp;
     }
     if ((double) step < KR_MIN_STEP) step = T(KR_MIN_STEP);
-    if (c.rlim > 0 && s.r + pr1 * step > c.rlim) step = kr_abs(dv<LeanDefault<T>::value>(c.rlim - s.r, pr1));
+    if (s.r + pr1 * step > c.rlim_clip) step = kr_abs(dv<LeanDefault<T>::value>(c.rlim - s.r, pr1));
     if (!USE_DEST) {
-        if (c.thetalim > 0 && s.theta + ptheta1 * step > c.thetalim) step = kr_abs(dv<LeanDefault<T>::value>(c.thetalim - s.theta, ptheta1));
+        if (s.theta + ptheta1 * step > c.thetalim_clip) step = kr_abs(dv<LeanDefault<T>::value>(c.thetalim - s.theta, ptheta1));
     }
 
     // flags (:264-273 / :874-887); neither ends the ray
     if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
-    if ((1 - dv<LeanDefault<T>::value>(2 * s.r, rhosq)) * pt1 + dv<LeanDefault<T>::value>(2 * a * s.r * sin2theta, rhosq) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
+    // (1 - 2r/rho^2) tdot + (2 a r sin^2/rho^2) phidot is the conserved energy k (= -p_t) evaluated from tdot and phidot: its two terms are
+    // <= ~(r^2 + a^2)^2 k / (rho^2 Delta) in size, so with r - r_horizon > 1e-6 (Delta > 1e-9 for every a < 0.99999) their rounding errors, 1e-16
+    // of the terms, stay below 1e-7 k: for k > 0 the sum cannot come out negative, in the reference or here.  The flag is therefore only
+    // evaluated -- with the reference's operations -- by waves in which some ray is that close to the horizon or has k <= 0 / NaN.
+    if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(!(s.r - c.horizon > T(1e-6)) || !(s.k > T(0))) != 0) {
+        if ((1 - dv_y<LeanDefault<T>::value>(2 * s.r, rhosq, y_rhosq)) * pt1 + dv_y<LeanDefault<T>::value>(2 * a * s.r * sin2theta, rhosq, y_rhosq) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
+    }
     }
 
     const T theta_prev = s.theta;
@@ -727,17 +836,21 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
                     eval<T, false>(pt, pr, ptheta, pphi, s, r_stage, s.theta + dtheta, a);
                 }
             };
+            // x1 + 2 x2 as ONE fused multiply-add: 2 x2 is exact, so fma(2, x2, x1) rounds the same sum once -- the reference's bits (:908-912)
+            // on either path, one instruction instead of two; the stage radius r + h pr is fused on the fast path only (the product rounds)
+            const T half = step / 2;
+            auto at = [&](T h, T v) -> T { if constexpr (FAST) return __builtin_fma(h, v, s.r); else return s.r + h * v; };
             T pt2, pr2, ptheta2, pphi2;
-            stage(pt2, pr2, ptheta2, pphi2, s.r + (step / 2) * pr1, (step / 2) * ptheta1);
-            acc_t = pt1 + 2 * pt2;
-            acc_phi = pphi1 + 2 * pphi2;
+            stage(pt2, pr2, ptheta2, pphi2, at(half, pr1), half * ptheta1);
+            acc_t = kr_fma2(pt2, pt1);
+            acc_phi = kr_fma2(pphi2, pphi1);
             T pt3, pr3, ptheta3, pphi3;
-            stage(pt3, pr3, ptheta3, pphi3, s.r + (step / 2) * pr2, (step / 2) * ptheta2);
-            acc_t = acc_t + 2 * pt3;
-            acc_phi = acc_phi + 2 * pphi3;
-            acc_r = pr1 + 2 * pr2 + 2 * pr3;
-            acc_theta = ptheta1 + 2 * ptheta2 + 2 * ptheta3;
-            stage(pt4, pr4, ptheta4, pphi4, s.r + step * pr3, step * ptheta3);
+            stage(pt3, pr3, ptheta3, pphi3, at(half, pr2), half * ptheta2);
+            acc_t = kr_fma2(pt3, acc_t);
+            acc_phi = kr_fma2(pphi3, acc_phi);
+            acc_r = kr_fma2(pr3, kr_fma2(pr2, pr1));
+            acc_theta = kr_fma2(ptheta3, kr_fma2(ptheta2, ptheta1));
+            stage(pt4, pr4, ptheta4, pphi4, at(step, pr3), step * ptheta3);
             return within;
         };
         if constexpr (FAST && KR_STAGE_SINCOS_NEAR) {
@@ -747,12 +860,31 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         }
         // x += (step/6)(k1 + 2k2 + 2k3 + k4), summed left to right as in :908-912
         const T w = FAST ? step * T(1.0 / 6.0) : div_const(step, T(6), T(1.0 / 6.0), true);
-        s.t += w * (acc_t + pt4);
-        s.r += w * (acc_r + pr4);
-        s.theta += w * (acc_theta + ptheta4);
-        s.phi += w * (acc_phi + pphi4);
+        if constexpr (FAST) {
+            s.t = __builtin_fma(w, acc_t + pt4, s.t);
+            s.r = __builtin_fma(w, acc_r + pr4, s.r);
+            s.theta = __builtin_fma(w, acc_theta + ptheta4, s.theta);
+            s.phi = __builtin_fma(w, acc_phi + pphi4, s.phi);
+        } else {
+            s.t += w * (acc_t + pt4);
+            s.r += w * (acc_r + pr4);
+            s.theta += w * (acc_theta + ptheta4);
+            s.phi += w * (acc_phi + pphi4);
+        }
     }
     if (crossed_equator(theta_prev, s.theta)) ++s.eq_cross;
+    if constexpr (FAST && !RK4 && KR_CARRY_SINCOS) {
+        // The next step's base point is theta_prev + dth with dth = theta - theta_prev EXACT (the two are within a factor of two of each other):
+        // its sin / cos follow from this step's by the angle addition the RK4 stages use -- 14 operations instead of the ~40 of a reduction,
+        // two polynomials and a quadrant fix-up.  Every addition leaves <= 1 ulp in the pair, as the integration leaves half an ulp in theta
+        // itself; every 1024th step of a ray, and whenever the increment is out of the addition's range or the ray went over a pole, the
+        // pair is taken afresh.
+        const T dth = s.theta - theta_prev;
+        double sn, cs;
+        sincos_near(aux.sn, aux.cs, dth, sn, cs);
+        s.carry_sin = sn; s.carry_cos = cs;
+        s.carry_ok = (__builtin_fabs(dth) <= sincos_near_limit(theta_prev)) && ((s.steps & 1023) != 0) && !(s.theta < T(0) || s.theta > T(kPi));
+    }
     reflect_poles(s.theta, s.phi, s.thetadot_sign);
 
     if (s.r <= c.horizon) { s.status |= KR_STATUS_HORIZON; return true; }
@@ -1143,7 +1275,7 @@ KR_DEV int32_t finish_status(Lane<T>& s, const TraceConsts<T>& c)
         s.status |= KR_STATUS_STEPLIM;
     else if (s.r >= c.rlim)
         s.status |= KR_STATUS_RLIM;
-    else if (!USE_DEST && ((c.thetalim > 0 && s.theta >= c.thetalim) || (c.thetalim < 0 && s.theta <= kr_abs(c.thetalim))))
+    else if (!USE_DEST && (s.theta >= c.theta_hi || s.theta <= c.theta_lo))       // (tl > 0 && theta >= tl) || (tl < 0 && theta <= |tl|)
         s.status |= KR_STATUS_DEST;
     int32_t out_steps = s.steps0;
     if (s.steps > 0) out_steps += s.steps;

@@ -47,6 +47,18 @@ static __device__ __forceinline__ double kr_fma3(double a, double b, double c)
 #else
 #define kr_fma3(a, b, c) __builtin_fma((a), (b), (c))
 #endif
+// the same with the addend in a SCALAR register pair (one SGPR operand is allowed per VALU instruction): for constants that are only live
+// for part of a step, so that they need neither a VGPR pair nor a v_mov_b64 to materialise them (kr_device.hpp::sincos_near)
+#if defined(__HIP_DEVICE_COMPILE__) && KR_ASM_FMA
+static __device__ __forceinline__ double kr_fma3s(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+#else
+#define kr_fma3s(a, b, c) __builtin_fma((a), (b), (c))
+#endif
 
 #ifndef KR_SGPR_COEFFS_STRICT
 #define KR_SGPR_COEFFS_STRICT 1
@@ -195,7 +207,13 @@ template <bool CR> KR_SC_FN void kr_sincos_general_t(double x, double& s, double
 #if KR_COMPACT_SINCOS
     const double ax = __builtin_fabs(x);
     if (__builtin_expect(!(ax < 1024.0), 0)) {
-        kr_sincos_libm_f64(x, &s, &c);
+        double ls, lc;                       // (locals: the caller's variables must not have their address handed to an out-of-line call,
+        kr_sincos_libm_f64(x, &ls, &lc);     // or the compiler keeps them in scratch memory on the hot path as well)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ls), "+v"(lc));   // values from here on, not loads the optimiser may merge with other memory
+#endif
+        s = ls;
+        c = lc;
         return;
     }
     const double t = __builtin_rint(x * 6.36619772367581382433e-01);        // 2/pi
@@ -241,12 +259,19 @@ template <bool CR> KR_SC_FN void kr_sincos_general_t(double x, double& s, double
 // ulp per operation: identical two-step Cody-Waite reduction, plain Horner kernels without the tail corrections
 // (sin: r + r z S(z), cos: 1 + z C(z); degree 13 / 14 as above), quadrant fix-up.  <= ~1.5 ulp for |x| < 1024, about 35
 // instructions against ~85 for the <1-ulp routine above.  Arguments outside that range take the routine above.
+KR_SC_FN void kr_sincos_fast_core_f64(double x, double& s, double& c);
 KR_SC_FN void kr_sincos_fast_f64(double x, double& s, double& c)
 {
     if (__builtin_expect(!(__builtin_fabs(x) < 1024.0), 0)) {
         kr_sincos_f64(x, s, c);
         return;
     }
+    kr_sincos_fast_core_f64(x, s, c);
+}
+
+// the routine proper, |x| < 1024 (the first reduction step is exact up to there; a polar angle after reflect_poles is in [0, pi]); NaN / inf in, NaN out
+KR_SC_FN void kr_sincos_fast_core_f64(double x, double& s, double& c)
+{
     const double t = __builtin_rint(x * 6.36619772367581382433e-01);
     const int n = (int) t;
     double r = __builtin_fma(-t, 1.57079632679489655800e+00, x);

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iterator>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -173,6 +174,7 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
     Lane<T> s;
     long long idx = -1;
     bool have = false;          // this lane holds a ray
+    bool pend = false;          // this lane's ray has ended and is still in its registers: written out at the wave's next visit to the queue (or on exit)
     bool exhausted = false;     // wave-uniform: the queue head has passed n
     unsigned long long my_steps = 0, my_traced = 0;
     uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
@@ -198,6 +200,13 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
             if (lane == leader) base = atomicAdd(&counters[0], (unsigned long long) n_need);
             base = __shfl(base, leader, 64);
             if (base + (unsigned long long) n_need >= (unsigned long long) n) exhausted = true;
+            if (pend) {
+                // (stored here, with every lane that has finished since the last visit, rather than under its own divergent branch in the
+                // step loop: that branch ran in one wave iteration out of nine for a single lane's ~40 instructions)
+                my_steps += (unsigned long long) s.steps;
+                store_ray(&rays[idx], s, finish_status<T, USE_DEST>(s, c));
+                pend = false;
+            }
             if (!have) {
                 const long long slot = (long long) base + __popcll(need & (lane_bit - 1));
                 if (slot < n && !(mask && mask[slot] != (unsigned char) mask_want)) {
@@ -216,6 +225,7 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
                         s.creep_run = 0;
                         s.creep_mode = false;
                         s.fsal_valid = false;
+                        s.carry_ok = false;
                         if (METHOD == KR_RK45) rk45_seed(s, c);
                         if (!loop_cond<T, USE_DEST>(s, c)) {
                             // zero-iteration call: only the epilogue runs
@@ -273,12 +283,14 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
             else if (METHOD == KR_RK4) fin = step_fixed<T, true, USE_DEST, FAST>(s, c);
             else fin = step_rk45<T, USE_DEST, FAST>(s, c, my_attempts, my_rejects, my_stationary, my_creep, replay_batch);
             if (fin) {
-                my_steps += (unsigned long long) s.steps;
-                const int32_t out_steps = finish_status<T, USE_DEST>(s, c);
-                store_ray(&rays[idx], s, out_steps);
                 have = false;
+                pend = true;
             }
         }
+    }
+    if (pend) {                                           // rays that ended after the wave's last visit to the queue
+        my_steps += (unsigned long long) s.steps;
+        store_ray(&rays[idx], s, finish_status<T, USE_DEST>(s, c));
     }
 
     // per-wave totals -> global counters (4 atomics per wave, once)
@@ -397,6 +409,7 @@ struct Workspace {
     int64_t mask_capacity = 0;
     std::vector<void*> retired;                  // outgrown masks (workspace_mask_reserve)
     hipStream_t side_stream = nullptr;                   // the second stream of a split trace: belongs to the caller's stream (side_stream_for)
+    hipStream_t strict_stream = nullptr;                 // KR_CU_PARTITION experiment: the strict side launch's own (CU-masked) stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;             // the whole trace, caller's stream
     hipEvent_t ev_strict0 = nullptr, ev_strict1 = nullptr; // strict side (+ overflow) launch, caller's stream
     hipEvent_t ev_main0 = nullptr, ev_main1 = nullptr;     // main launch of a split, side stream
@@ -427,6 +440,22 @@ constexpr int kMaxMultiGrid = 32768;                     // single-wave workgrou
 constexpr size_t kMaxSideStreams = 16;
 std::map<hipStream_t, hipStream_t> g_side_streams[64];
 
+// EXPERIMENT (KR_CU_PARTITION=<k>, default off): the strict side launch on a stream whose queue may only use the first k compute units, the main
+// launch on one that may only use the others -- the critical rays' waves then share no CU (instruction cache, scalar cache, issue arbitration)
+// with the main launch's.  Measured: profiles/r03_ab_experiments.txt.
+int cu_partition()
+{
+    static const int k = [] { const char* e = getenv("KR_CU_PARTITION"); return e ? atoi(e) : 0; }();
+    return k;
+}
+hipError_t masked_stream(hipStream_t* s, int first, int count)
+{
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = first; i < first + count && i < 256; i++) mask[i / 32] |= 1u << (i % 32);
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+}
+std::map<hipStream_t, hipStream_t> g_strict_streams[64];
+
 int side_stream_for(int dev, hipStream_t user, hipStream_t* out)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -444,7 +473,16 @@ int side_stream_for(int dev, hipStream_t user, hipStream_t* out)
         int prio = least;
         if (const char* e = getenv("KR_SIDE_STREAM_PRIORITY")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "default") ? 0 : least;
         hipStream_t s = nullptr;
-        KR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+        if (cu_partition() > 0) {
+            int cus = 0;
+            KR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            KR_HIP(masked_stream(&s, cu_partition(), cus - cu_partition()));
+            hipStream_t st = nullptr;
+            KR_HIP(masked_stream(&st, 0, cu_partition()));
+            g_strict_streams[dev][user] = st;
+        } else {
+            KR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+        }
         it = table.emplace(user, s).first;
     }
     *out = it->second;
@@ -575,6 +613,13 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
     }
     c.steplim = steplim;
     c.stop_kind = p->stop_kind;
+    const T inf = std::numeric_limits<T>::infinity();
+    c.theta_lo = c.thetalim < 0 ? std::fabs(c.thetalim) : -inf;
+    c.theta_hi = c.thetalim > 0 ? c.thetalim : (c.thetalim <= 0 ? inf : -inf);
+    c.tstep_rlim_eff = c.max_tstep > 0 ? c.maxtstep_rlim : -inf;
+    c.phistep_eff = c.max_phistep > 0 ? c.max_phistep : inf;
+    c.rlim_clip = c.rlim > 0 ? c.rlim : inf;
+    c.thetalim_clip = c.thetalim > 0 ? c.thetalim : inf;
     return c;
 }
 
@@ -692,6 +737,11 @@ int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wo
     hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, ws->mask, ws->list, split_words + 1);
     KR_HIP(hipGetLastError());
     KR_HIP(hipEventRecord(ws->ev_classified, stream));
+    hipStream_t caller = stream;
+    if (ws->strict_stream) {
+        stream = ws->strict_stream;
+        KR_HIP(hipStreamWaitEvent(stream, ws->ev_classified, 0));
+    }
     KR_HIP(hipEventRecord(ws->ev_strict0, stream));
     // strict side launch: one wave, alone on its SIMD, per 64 listed rays, on at most half of the chip
     ListArgs strict_la;
@@ -703,6 +753,7 @@ int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wo
     const int rc = launch_f64<false, true>(p, rays, list_max, c, ws->counters + kCounters, ws->cus, stream, 1, strict_la);
     if (rc != KR_OK) return rc;
     KR_HIP(hipEventRecord(ws->ev_strict1, stream));
+    if (ws->strict_stream) KR_HIP(hipStreamWaitEvent(caller, ws->ev_strict1, 0));
     ws->split = true;
     return KR_OK;
 }
@@ -822,6 +873,12 @@ int trace_front(Pending& t, bool batch)
     if (t.split) {
         rc = side_stream_for(ws->device, t.stream, &ws->side_stream);
         if (rc != KR_OK) return rc;
+        ws->strict_stream = nullptr;
+        if (cu_partition() > 0) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            auto it = g_strict_streams[ws->device].find(t.stream);
+            if (it != g_strict_streams[ws->device].end()) ws->strict_stream = it->second;
+        }
         return split_front(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream);
     }
     return KR_OK;
@@ -1122,6 +1179,8 @@ int trace_shutdown()
         for (auto& kv : g_side_streams[dev])
             if (std::find(seen.begin(), seen.end(), kv.second) == seen.end()) { seen.push_back(kv.second); (void) hipStreamDestroy(kv.second); }
         g_side_streams[dev].clear();
+        for (auto& kv : g_strict_streams[dev]) (void) hipStreamDestroy(kv.second);
+        g_strict_streams[dev].clear();
     }
     if (have_dev) (void) hipSetDevice(keep);
     (void) hipGetLastError();

@@ -51,7 +51,9 @@ for kind, tag, spec, spin, V in configs:
     want = src.snapshot()
     src.close()
     valid = want["steps"] != -1
-    row = {"config": tag, "stop": STOP, "rays": int(valid.sum()), "cpu_s": round(cpu_s, 2)}
+    # what Raytracer<T>::run_raytrace picks when KRTRACE_ARITHMETIC is unset (host/raytracer/raytracer.cpp::arithmetic_flags)
+    row = {"config": tag, "stop": STOP, "rays": int(valid.sum()), "cpu_s": round(cpu_s, 2),
+           "class_mirror_default": "strict" if (STOP != "theta" or METHOD == capi.RK45) else "hybrid"}
     modes = (("hybrid", capi.FLAG_HYBRID), ("strict", 0)) + ((("strict_iterate_all", capi.FLAG_RK45_ITERATE_ALL),) if METHOD == capi.RK45 else ())
     for mode, flags in modes:
         got, st = api.trace(capi.copy_params(p, flags=flags), init)
