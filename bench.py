@@ -139,7 +139,7 @@ def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
     """Times the CPU path on this box's host cores -- the reference's own run_raytrace (oracle/_ref) where it was built, else the oracle port --
     and checks the GPU results ray by ray and bin by bin against it.  Two legs:
       * thread sweep: the reference's `omp parallel for schedule(dynamic)` with an `omp atomic` progress counter (raytracer.cpp:104-124) does not
-        scale to every hardware thread of a 256-thread host, so a ~1e6-ray sample of the workload is timed at 64 / 128 / 256 threads (those the
+        scale to every hardware thread of a 256-thread host, so a ~1e6-ray sample of the workload is timed at 16 / 32 / 64 / 128 / 256 threads (those the
         box has) and the best team size is kept;
       * the headline grid ITSELF (3162^2 rays, what `value` of the GPU line is quoted on) at that team size -- unless the sweep says it would take
         more than ~90 s, or --cpu-sample-rays asks for a sample; the checks then run on the same rays the timing ran on."""
@@ -176,7 +176,7 @@ def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
 
     # leg 1: team size
     sweep = {}
-    teams = sorted({t for t in (64, 128, 256) if t <= cores} | {cores}) if cores > 64 else [cores]
+    teams = sorted({t for t in (16, 32, 64, 128, 256) if t <= cores} | {cores}) if cores > 16 else [cores]
     d_sweep = grid_spacing_for(min(1.0e6, 25000.0 * cores))
     for t in teams:
         _, _, out_t, wall_t = run_cpu(d_sweep, t)

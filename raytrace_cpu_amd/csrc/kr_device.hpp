@@ -931,8 +931,8 @@ KR_DEV void rk45_seed(Lane<T>& s, const TraceConsts<T>& c)
 
     T step = kr_abs((r - c.horizon) / s.pr) / c.precision;
     if (kr_abs(s.ptheta) > 0 && step > kr_abs(theta / s.ptheta) / c.theta_precision) step = kr_abs(theta / s.ptheta) / c.theta_precision;
-    if (c.max_tstep > 0 && r < c.maxtstep_rlim && step > kr_abs(c.max_tstep / s.pt)) step = kr_abs(c.max_tstep / s.pt);
-    if (c.max_phistep > 0 && step > kr_abs(c.max_phistep / s.pphi)) step = kr_abs(c.max_phistep / s.pphi);
+    if (r < c.tstep_rlim_eff && step > kr_abs(c.max_tstep / s.pt)) step = kr_abs(c.max_tstep / s.pt);
+    if (step > kr_abs(c.phistep_eff / s.pphi)) step = kr_abs(c.phistep_eff / s.pphi);
     if ((double) step < KR_MIN_STEP) step = T(KR_MIN_STEP);
     s.step = step;
     s.theta_eq_prev = theta;
@@ -1030,11 +1030,11 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
             const T two_r_rho = 2 * s.r * aux.inv_rhosq;
             if ((1 - two_r_rho) * s.pt + (two_r_rho * a * aux.sin2theta) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
             step_max = kr_abs((s.r - c.horizon) * fast_rcp(s.pr)) * c.inv_precision;
-            if (c.max_phistep > 0) {
-                const T step_phi = kr_abs(c.max_phistep * fast_rcp(s.pphi));
+            {                                              // (switched off: phistep_eff = +inf, tstep_rlim_eff = -inf -- TraceConsts)
+                const T step_phi = kr_abs(c.phistep_eff * fast_rcp(s.pphi));
                 if (step_phi < step_max) step_max = step_phi;
             }
-            if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
+            if (s.r < c.tstep_rlim_eff) {
                 const T step_t = kr_abs(c.max_tstep * fast_rcp(s.pt));
                 if (step_t < step_max) step_max = step_t;
             }
@@ -1054,11 +1054,11 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
         if ((1 - 2 * s.r / rhosq) * s.pt + (2 * a * s.r * sin2theta / rhosq) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
         // outer cap (:1421-1434): horizon / phi / t, no MIN_STEP floor afterwards
         step_max = kr_abs((s.r - c.horizon) / s.pr) / c.precision;
-        if (c.max_phistep > 0) {
-            const T step_phi = kr_abs(c.max_phistep / s.pphi);
+        {                                                  // max_phistep > 0: otherwise the quotient is inf / NaN and the comparison false
+            const T step_phi = kr_abs(c.phistep_eff / s.pphi);
             if (step_phi < step_max) step_max = step_phi;
         }
-        if (c.max_tstep > 0 && s.r < c.maxtstep_rlim) {
+        if (s.r < c.tstep_rlim_eff) {                      // max_tstep > 0 && r < maxtstep_rlim
             const T step_t = kr_abs(c.max_tstep / s.pt);
             if (step_t < step_max) step_max = step_t;
         }
@@ -1073,12 +1073,12 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T h_try = s.step;
     bool clamped = false;
     if (!USE_DEST) {
-        if (c.thetalim > 0 && theta + ptheta1 * h_try > c.thetalim) {
+        if (theta + ptheta1 * h_try > c.thetalim_clip) {      // thetalim > 0 && ...
             const T h_th = kr_abs((c.thetalim - theta) / ptheta1);
             if (h_th < h_try) { h_try = h_th; clamped = true; }
         }
     } else {
-        if (c.rlim > 0 && r + pr1 * h_try > c.rlim) { h_try = kr_abs((c.rlim - r) / pr1); clamped = true; }
+        if (r + pr1 * h_try > c.rlim_clip) { h_try = kr_abs((c.rlim - r) / pr1); clamped = true; }      // rlim > 0 && ...
         const T h_dest = dest_step_limit(c, r, theta, ptheta1);
         if (h_dest < h_try) { h_try = h_dest; clamped = true; }
     }

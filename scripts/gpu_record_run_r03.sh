@@ -1,0 +1,28 @@
+#!/bin/bash
+# GPU box: round-3 record run -- every bench workload, the RK45 sweep, rocprofv3 kernel trace + PMC passes of the headline.  (The full GPU suite is a call of its own.)
+cd ${GRAFT_REPO_ROOT:-.}
+O=gpurun_out/record_r03; mkdir -p $O
+timeout -k 10 900 python bench.py > $O/bench_n1_emissivity.json 2> $O/err_emis.txt || tail -3 $O/err_emis.txt
+timeout -k 10 300 python bench.py --workload imageplane > $O/bench_n1_imageplane.json 2> $O/err_ip.txt || tail -3 $O/err_ip.txt
+timeout -k 10 300 python bench.py --workload return_radiation --no-cpu-baseline > $O/bench_n1_return_radiation.json 2> $O/err_rr.txt || tail -3 $O/err_rr.txt
+timeout -k 10 300 python bench.py --integrator rk45 --no-cpu-baseline > $O/bench_n1_emissivity_rk45.json 2> $O/err_rk45.txt || tail -3 $O/err_rk45.txt
+timeout -k 10 300 python bench.py --integrator euler --no-cpu-baseline > $O/bench_n1_emissivity_euler.json 2> $O/err_eu.txt || tail -3 $O/err_eu.txt
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --no-cpu-baseline --no-fast-math-extra --workload imageplane > $O/bench_torchrun1_imageplane.json 2> $O/err_tr.txt || tail -5 $O/err_tr.txt
+python bench.py --gpus 2 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_gpus2_on_one_gpu.out 2> $O/bench_gpus2_on_one_gpu.err; echo "bench.py --gpus 2 on this 1-GPU box: rc=$?" | tee $O/bench_gpus2_rc.txt; grep -m2 "wants GPU\|starting" $O/bench_gpus2_on_one_gpu.err
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/record_r03/bench_*.json")):
+    for l in open(f):
+        if l.startswith("{"):
+            d = json.loads(l)
+            print(f.split("/")[-1], "%.3e rays/s %.3e steps/s ms %.1f kern %.1f frac %.3f" % (d["value"], d["rk_steps_per_sec"], d["ms_per_step"], d["roofline"]["avg_kernel_ms"], d["roofline"]["frac"]), d["scaling"], d["roofline"].get("split_launch_ms"), d.get("rk45"))
+            if "cpu_baseline" in d:
+                c = d["cpu_baseline"]; print("   cpu_baseline", {k: c[k] for k in ("value", "cores", "kind", "wall_s") if k in c}, c.get("sample", "")[:80], c.get("rays_check"), c.get("bins_check"))
+PY
+timeout -k 10 600 python scripts/rk45_tol_sweep.py strict > $O/rk45_tol_sweep_strict.json 2> $O/err_sweep.txt
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/record_r03/rk45_tol_sweep_strict.json"))
+print("sweep strict", [(r["h"], r["tol"], round(r["kernel_ms"])) for r in d["runs"] if r["integrator"] == "rk45"][::4], {k: v for k, v in d["concurrent"].items() if k != "per_point_span_ms"})
+PY
+scripts/profile_round.sh r03 > $O/profile.log 2>&1; tail -3 $O/profile.log

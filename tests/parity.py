@@ -127,6 +127,10 @@ def noise_envelope_frac(params, init, rtol):
 
 
 MAX_BAD_FRAC = 0.05
+# The fast arithmetic on the Keplerian-source fixture: on the 320-ray grid 4.4-4.7 % of the rays sit beyond 1e-9 (reference's own 1-ulp envelope
+# 2.8-3.4 %) -- a coarse-grid artefact, the same geometry on 5040 rays leaves 1.13-1.15 % (envelope 0.9-1.0 %; profiles/r03_parity_margins.json).
+# The large fixture is therefore held to twice its measured share, so that a regression of the arithmetic shows; the small one keeps the global cap.
+HYBRID_CAP = {"ps_kep5k": 0.023}
 STRICT_BAD_FRAC = 1e-3      # fixed-step integrators on the strict arithmetic: measured 0 bad rays on every PointSource fixture, 2 of 289 on the
 STRICT_BAD_RAYS = 2.5       # image-plane grid that contains the x = 0 column and the NaN pixel (profiles/r02_parity_margins.json)
 
