@@ -232,8 +232,8 @@ template <typename T> struct TraceConsts {
     // decisions on every ray, and no uniform lane masks for the compiler to carry (and spill) through the step loop.
     T tstep_rlim_eff;       // max_tstep > 0 ? maxtstep_rlim : -inf
     T phistep_eff;          // max_phistep > 0 ? max_phistep : +inf
-    T rlim_clip;            // rlim > 0 ? rlim : +inf
-    T thetalim_clip;        // thetalim > 0 ? thetalim : +inf
+    // ("rlim > 0 && r + rdot step > rlim" needs no constant of its own: with rlim <= 0 the loop condition r < rlim admits no step at all.
+    // Likewise "thetalim > 0 && theta + thetadot step > thetalim" compares against theta_hi below: +inf unless thetalim > 0.)
     // loop condition of the theta-limit overloads, (tl > 0 && theta < tl) || (tl < 0 && theta > |tl|) || tl == 0  (:799), as theta_lo < theta < theta_hi:
     // tl > 0: (-inf, tl);  tl < 0: (|tl|, +inf);  tl == 0: (-inf, +inf);  NaN: empty (theta_hi = -inf)
     T theta_lo, theta_hi;
@@ -746,17 +746,17 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         // the two landing clips apply on a ray's LAST step only: one fused test each, the clip itself behind a wave-uniform branch (the empty
         // asm keeps the compiler from turning the branch back into unconditional arithmetic and selects)
         {
-            const bool clip_r = __builtin_fma(pr1, step, s.r) > c.rlim_clip;
+            const bool clip_r = __builtin_fma(pr1, step, s.r) > c.rlim;
             if (__builtin_amdgcn_ballot_w64(clip_r) != 0) {
                 asm volatile("" ::: "memory");
                 if (clip_r) step = kr_abs(c.rlim - s.r) * inv_pr;
             }
         }
         if (!USE_DEST) {
-            const bool clip_th = __builtin_fma(ptheta1, step, s.theta) > c.thetalim_clip;
+            const bool clip_th = __builtin_fma(ptheta1, step, s.theta) > c.theta_hi;
             if (__builtin_amdgcn_ballot_w64(clip_th) != 0) {
                 asm volatile("" ::: "memory");
-                if (clip_th) step = kr_abs(c.thetalim - s.theta) * inv_pth;
+                if (clip_th) step = kr_abs(c.theta_hi - s.theta) * inv_pth;
             }
         }
         if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
@@ -787,9 +787,9 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         if (step > sp) step = sp;
     }
     if ((double) step < KR_MIN_STEP) step = T(KR_MIN_STEP);
-    if (s.r + pr1 * step > c.rlim_clip) step = kr_abs(dv<LeanDefault<T>::value>(c.rlim - s.r, pr1));
+    if (s.r + pr1 * step > c.rlim) step = kr_abs(dv<LeanDefault<T>::value>(c.rlim - s.r, pr1));
     if (!USE_DEST) {
-        if (s.theta + ptheta1 * step > c.thetalim_clip) step = kr_abs(dv<LeanDefault<T>::value>(c.thetalim - s.theta, ptheta1));
+        if (s.theta + ptheta1 * step > c.theta_hi) step = kr_abs(dv<LeanDefault<T>::value>(c.theta_hi - s.theta, ptheta1));
     }
 
     // flags (:264-273 / :874-887); neither ends the ray
@@ -1073,12 +1073,12 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T h_try = s.step;
     bool clamped = false;
     if (!USE_DEST) {
-        if (theta + ptheta1 * h_try > c.thetalim_clip) {      // thetalim > 0 && ...
-            const T h_th = kr_abs((c.thetalim - theta) / ptheta1);
+        if (theta + ptheta1 * h_try > c.theta_hi) {      // thetalim > 0 && ...
+            const T h_th = kr_abs((c.theta_hi - theta) / ptheta1);      // (= thetalim: the clamp only fires for thetalim > 0)
             if (h_th < h_try) { h_try = h_th; clamped = true; }
         }
     } else {
-        if (r + pr1 * h_try > c.rlim_clip) { h_try = kr_abs((c.rlim - r) / pr1); clamped = true; }      // rlim > 0 && ...
+        if (r + pr1 * h_try > c.rlim) { h_try = kr_abs((c.rlim - r) / pr1); clamped = true; }      // rlim > 0 && ...
         const T h_dest = dest_step_limit(c, r, theta, ptheta1);
         if (h_dest < h_try) { h_try = h_dest; clamped = true; }
     }

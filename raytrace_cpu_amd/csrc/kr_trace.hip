@@ -618,8 +618,6 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
     c.theta_hi = c.thetalim > 0 ? c.thetalim : (c.thetalim <= 0 ? inf : -inf);
     c.tstep_rlim_eff = c.max_tstep > 0 ? c.maxtstep_rlim : -inf;
     c.phistep_eff = c.max_phistep > 0 ? c.max_phistep : inf;
-    c.rlim_clip = c.rlim > 0 ? c.rlim : inf;
-    c.thetalim_clip = c.thetalim > 0 ? c.thetalim : inf;
     return c;
 }
 
