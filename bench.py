@@ -424,6 +424,8 @@ class ReturnRadiationWorkload:
         self.nstreams, self.streams, self.buffers, self.order, self.ordered = max(0, args.streams), None, None, None, False
         self.p = capi.default_params(SPIN)
         self.p.integrator, self.p.r_max = self.method, 1.1 * R_MAX
+        if os.environ.get("KR_RR_BLOCKS"):                 # experiment: resident waves per SIMD of the merged main launch (scripts/gpu_euler_occ.sh)
+            self.p.flags |= (int(os.environ["KR_RR_BLOCKS"]) & 0xF) << 8
         self.result_words = 4 * self.nr
         self.describe = (f"disc->disc returning radiation: {self.nr} source radii r_isco..500 x ~{int(rays)} rays (beta in [0,pi)), {args.integrator.upper()}, "
                          f"r_max=1.1*r_esc, per-radius relaunch (BASELINE configs[4])")

@@ -1138,7 +1138,18 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     const T err_theta = h_try * (D::e1 * ptheta1 + D::e3 * ptheta3 + D::e4 * ptheta4 + D::e5 * ptheta5 + D::e6 * ptheta6 + D::e7 * ptheta7);
     const T sc_r = c.tol * (T(1) + std_max(kr_abs(r), kr_abs(r_new)));
     const T sc_theta = c.tol * (T(1) + std_max(kr_abs(theta), kr_abs(theta_new)));
-    const T err_norm = kr_sqrt(T(0.5) * ((err_r / sc_r) * (err_r / sc_r) + (err_theta / sc_theta) * (err_theta / sc_theta)));
+    // The norm itself is never stored: it only decides -- accept (<= 1), the controller's factor (5 whenever <= 1.8e-4, below), the creep test
+    // (<= 0.5).  A ray whose step is set by a cap rather than by its error (the polar-axis ray's 100 000 steps, which bound every RK45 launch)
+    // sits orders of magnitude below 1.8e-4: two raw reciprocals (2^-22) show that with a 1 % margin, every decision is then known, and the two
+    // IEEE quotients and the IEEE root (36 instructions of a lone wave's ~1000 per trial) are left out.  Wave-uniform; NaN takes the exact path.
+    T err_norm;
+    bool surely_saturated = false;
+    if constexpr (sizeof(T) == 8) {
+        const double qr = (double) err_r * __builtin_amdgcn_rcp((double) sc_r), qt = (double) err_theta * __builtin_amdgcn_rcp((double) sc_theta);
+        surely_saturated = __builtin_fma(qr, qr, qt * qt) <= 6.4e-8;                 // (1.8e-4)^2 x 2 = 6.48e-8
+    }
+    if (__builtin_amdgcn_ballot_w64(!surely_saturated) == 0) err_norm = T(1e-4);      // (stands for "some value <= 1.8e-4")
+    else err_norm = kr_sqrt(T(0.5) * ((err_r / sc_r) * (err_r / sc_r) + (err_theta / sc_theta) * (err_theta / sc_theta)));
 
     // 0.9 (1 / max(err, 1e-10))^0.2 clamped to [0.1, 5] (:1517-1518) IS 5 whenever err <= 1.889e-4 (0.9 x^0.2 >= 5 from x = 5292 on); a ray
     // whose step is set by a cap rather than by its error -- the polar-axis ray's 100 000 steps -- is there at every step, and the

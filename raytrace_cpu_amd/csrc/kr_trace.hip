@@ -143,7 +143,11 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 #ifndef KR_RK4_MIN_WAVES
 #define KR_RK4_MIN_WAVES 3
 #endif
-#define KR_HOG_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? KR_RK4_MIN_WAVES : METHOD == KR_RK45 ? 2 : 1, HOG ? KR_HOG_MAX_WAVES : 8)))
+#ifndef KR_EULER_MIN_WAVES
+#define KR_EULER_MIN_WAVES 4   // the Euler step is short and branchy (173 vector + ~100 scalar instructions, ~25 branches): at 3 waves per SIMD the vector
+                               // unit is 78 % busy; 1e7 rays 38.5 / 31.4 / 28.3 ms at 2 / 3 / 4 resident waves (profiles/r03_ab_experiments.txt)
+#endif
+#define KR_HOG_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? KR_RK4_MIN_WAVES : METHOD == KR_RK45 ? 2 : KR_EULER_MIN_WAVES, HOG ? KR_HOG_MAX_WAVES : 8)))
 #endif
 // everything one trace launch works on; a batch of traces hands the kernel an array of these (trace_multi_kernel)
 template <typename T> struct TraceDesc {
@@ -654,7 +658,7 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     //   ImagePlane 4097^2 rays (longest ~2 000 steps)     480 / 344 / 318      fast-math 1e7 rays   176 / 121 / 110
     // Default: 3 when the launch is long enough for throughput to dominate (n >= 2e7, or fast-math with n >= 5e6),
     // else 2.  kr_params.flags bits 8..11 (KR_FLAG_BLOCKS_PER_CU) or the KR_BLOCKS_PER_CU environment variable override.
-    int want = max_blocks_per_cu > 0 ? max_blocks_per_cu : ((n >= 20000000 || (FAST && n >= 5000000)) ? 3 : 2);
+    int want = max_blocks_per_cu > 0 ? max_blocks_per_cu : (METHOD == KR_EULER && FAST) ? 4 : ((n >= 20000000 || (FAST && n >= 5000000)) ? 3 : 2);
     if (const char* e = getenv("KR_BLOCKS_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1) want = v;
@@ -767,8 +771,9 @@ int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wor
     ListArgs main_la;
     main_la.mask = ws->mask;
     main_la.mask_want = 0;
-    int rc = fast_main ? launch_f64<true, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, mb ? mb : 3, main_la)
-                       : launch_f64<false, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, mb ? mb : 3, main_la);
+    const int main_waves = mb ? mb : (fast_main && p->integrator == KR_EULER) ? 4 : 3;      // resident waves per SIMD of the main launch
+    int rc = fast_main ? launch_f64<true, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, main_waves, main_la)
+                       : launch_f64<false, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, main_waves, main_la);
     if (rc != KR_OK) return rc;
     // strict overflow launch (mask == 2): only has work when more than kListCap rays were flagged, and then the main launch has
     // next to none.  It follows the main launch on the side stream: behind the side launch on the caller's stream its idle
@@ -1001,7 +1006,7 @@ int merged_batch(std::vector<Pending>& ts, bool hybrid)
     // main launch: twice what is resident (3 waves per SIMD), never more waves than 64-ray loads; wave -> trace in proportion to the
     // traces' ray counts, interleaved so that the first waves to be placed cover every trace
     const int mb = KR_FLAG_GET_BLOCKS_PER_CU(p0->flags);
-    const int64_t resident = (int64_t) w0->cus * 4 * (mb ? mb : 3);
+    const int64_t resident = (int64_t) w0->cus * 4 * (mb ? mb : (hybrid && p0->integrator == KR_EULER) ? 4 : 3);
     const int main_grid = (int) std::max<int64_t>(count, std::min<int64_t>({main_waves, 2 * resident, (int64_t) kMaxMultiGrid}));
     int* wave_trace = (int*) ((char*) w0->h_descs + table_off);
     {
