@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 11
+#define KR_ABI_VERSION 12
 
 /* error codes */
 #define KR_OK          0
@@ -301,6 +301,15 @@ int kr_imageplane_init_strided_dev_f64(const kr_imageplane* s, int64_t first, in
  * (raytracer.cpp:603-622, :420-553, emissivity.cpp:96-126); rays[] ends up exactly as after the separate calls. */
 int kr_pointsource_init_emit_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d_rays, int64_t count,
                                      void* stream);
+/* The emissivity pipeline of src/emissivity/emissivity.cpp:60-126 -- PointSource ctor, redshift_start(V_start, ...), run_raytrace(theta_max, r_max),
+ * redshift(V, ...), radial histogram -- as ONE trace whose rays never exist in memory: a lane builds source ray `first + slot * stride` in
+ * registers when it takes slot `slot` (0 <= slot < count) off the work queue and adds the finished ray to the histogram (LDS per workgroup,
+ * one global atomic per non-empty word on exit).  Same per-ray functions as kr_pointsource_init_emit_dev_f64 + kr_trace_dev_f64 +
+ * kr_post_emissivity_dev_f64, so counts are identical and sums differ only in the order of addition.  p: the trace's parameters (theta-limit
+ * overload; flags as for kr_trace_*); d_hist: 5 nr + 1 doubles, ADDED to (zero it first); stats may be null (then the call does not wait). */
+int kr_emissivity_pipeline_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, int64_t count, double V_start, int32_t reverse_start,
+                                   int32_t projradius_start, const kr_params* p, double spin, double V, int32_t reverse, int32_t projradius, int32_t motion,
+                                   const kr_emis_bins* bins, void* d_hist, void* stream, kr_stats* stats);
 /* the same for the image pipeline: ImagePlane ctor + redshift_start(V, reverse, projradius) (imageplane.cpp:11-121; the negated spin
  * of the ImagePlane is applied inside), and redshift(V, reverse, projradius, motion) + range_phi(lo, hi) + the seven planes of
  * kr_reduce_image_dev_f64 (imageplane_disc_image.cpp:117-161; `spin` as stored by the Raytracer, i.e. negated) */

@@ -36,6 +36,7 @@
 
 #include "kr_common.hpp"
 #include "kr_device.hpp"
+#include "kr_post_device.hpp"
 
 namespace kr {
 
@@ -48,6 +49,16 @@ constexpr int kBlock = 256;          // classification kernel
 #endif
 constexpr int kTraceBlock = KR_TRACE_BLOCK;
 constexpr int kWavesPerBlock = kTraceBlock / 64;
+// HOG instances (the strict side launch): one wave per workgroup too, and the first claims are static (wave g takes list slots 64 g ..), so the
+// listed rays go to the lowest-numbered workgroups -- which the dispatcher spreads over as many compute units -- and every other workgroup leaves
+// at once.  -DKR_HOG_BLOCK=256 puts four such waves in a workgroup, which then owns its compute unit (no wave of the main launch beside the
+// critical rays' waves): MEASURED WORSE -- four lone waves on one CU slow one another down more than nine waves of the main launch do (RK45 1e7
+// rays 385 -> 411 ms, Euler 36.5 -> 38.1, RK4 headline 72.2 -> 71.7: profiles/r03_ab_experiments.txt).
+#ifndef KR_HOG_BLOCK
+#define KR_HOG_BLOCK 64
+#endif
+constexpr int kHogBlock = KR_HOG_BLOCK;
+constexpr int block_of(bool hog) { return hog ? kHogBlock : kTraceBlock; }
 // A wave goes back to the queue when at least this many of its lanes are free (or none holds a ray).  The refill / finish / store code runs with
 // only the free lanes active, ~500 vector instructions per visit -- as much as an RK4 step: visiting for every single finished lane cost the image
 // plane (1.25 lanes per visit) 11 % and the Euler launches 26 %; waiting for 4 leaves ~1.5 lanes of 64 idle on average.
@@ -120,6 +131,55 @@ KR_DEV void store_ray(kr_ray_f32* p, const Lane<float>& s, int32_t out_steps)
     p->rdot_flips = s.rdot_flips; p->equatorial_crossings = s.eq_cross;
 }
 
+// ---- where a trace kernel's rays come from and where they go ---------------------------------------------------------
+// RecordIO: the reference's own records in HBM (every entry point of the class API).
+template <typename T> struct RecordIO {
+    typename RayOf<T>::type* __restrict__ rays;
+    KR_DEV long long load(long long i, Lane<T>& s) const { load_ray(&rays[i], s); return i; }      // (returns what store() is to be handed)
+    KR_DEV void store(long long i, const Lane<T>& s, int32_t out_steps) const { store_ray(&rays[i], s, out_steps); }
+};
+
+// EmissivityPipe (kr_emissivity_pipeline_dev_f64): NO ray record exists in memory.  A lane that takes slot i off the queue
+// builds PointSource ray first + i stride in registers (pointsource.cpp:30-64 + calculate_constants, raytracer.cpp:625-676) and, when the ray has
+// ended, redshifts it (redshift_start's `emit` is recomputed from the source ray -- a few hundred instructions against ~500 steps of ~400 --
+// rather than carried through the step loop in two more registers; raytracer.cpp:342-417, :420-553) and adds it to the workgroup's copy of the
+// radial histogram in LDS (emissivity.cpp:96-126), which is flushed with one global atomic per non-empty word when the wave leaves.  The
+// per-ray functions are the ones the streaming kernels of kr_post.hip use (kr_post_device.hpp): same bits per ray; the histogram's sums differ
+// from theirs only in the order of addition.
+// The two ends are inlined ONCE each: trace_body loads a ray in one place and stores one in one place.  (As out-of-line calls they left the
+// register allocator with half the file across the call sites and the step loop full of spills: main launch 65 -> 85 ms.  Inlined at the three
+// store sites the loop used to have, every pipeline instance was 110-150 KB of code against a 64-KB instruction cache.)
+// (`emit`, redshift_start's result, depends on the ray only through k, h, Q -- which the lane keeps -- and the two INITIAL direction signs: those
+// ride in the top bits of the lane's 64-bit slot index (tag), so the store path need not build the source ray a second time.)
+struct EmisPipeIO {
+    const EmisPipeArgs* a;
+    double* acc;                // LDS copy of the histogram, or a->hist
+    double a_start, V_start;    // redshift_start's effective spin and (resolved) velocity
+    double log_dr;              // log of the bin ratio, from the device's log like the streaming reducer's
+    static constexpr long long kTagR = 1ll << 62, kTagTheta = 1ll << 61, kIndexMask = kTagTheta - 1;
+    KR_DEV long long load(long long i, Lane<double>& s) const
+    {
+        const kr_ray_f64 r = pointsource_ray(a->src, a->n_grid, a->n_beta, a->first + i * a->stride);
+        s.t = r.t; s.r = r.r; s.theta = r.theta; s.phi = r.phi;
+        s.pt = 0; s.pr = 0; s.ptheta = 0; s.pphi = 0;
+        s.k = r.k; s.h = r.h; s.Q = r.Q;
+        s.steps0 = r.steps; s.status = r.status; s.rdot_sign = r.rdot_sign; s.thetadot_sign = r.thetadot_sign;
+        s.rdot_flips = r.rdot_flips; s.eq_cross = r.equatorial_crossings;
+        return i | (r.rdot_sign < 0 ? kTagR : 0) | (r.thetadot_sign < 0 ? kTagTheta : 0);
+    }
+    KR_DEV void store(long long tagged, const Lane<double>& s, int32_t out_steps) const
+    {
+        kr_ray_f64 v;
+        v.r = a->src.pos[1]; v.theta = a->src.pos[2];              // where every ray of the source starts
+        v.k = s.k; v.h = s.h; v.Q = s.Q;
+        v.rdot_sign = (tagged & kTagR) ? -1 : 1; v.thetadot_sign = (tagged & kTagTheta) ? -1 : 1;
+        v.emit = emit_value(v, a->src.spin, a_start, V_start, a->reverse_start);
+        v.r = s.r; v.theta = s.theta; v.rdot_sign = s.rdot_sign; v.thetadot_sign = s.thetadot_sign;
+        const double g = redshift_value(v, a->spin, a->V, a->reverse, a->projradius, a->motion);
+        emissivity_accumulate(acc, a->bins, log_dr, out_steps, s.r, s.theta, g, s.t);
+    }
+};
+
 template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 {
 #pragma unroll
@@ -161,10 +221,10 @@ template <typename T> struct TraceDesc {
     int n_mode, mask_want;
 };
 
-template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
-KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, const TraceConsts<T>& c, unsigned long long* __restrict__ counters,
+template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN, class IO>
+KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsigned long long* __restrict__ counters,
                        const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want,
-                       int& has_prio)
+                       int& has_prio, long long first_slot = -1, unsigned long long head_offset = 0)
 {
     if (n_ptr) {
         // the item count was produced on the device (classify_kernel) and never visits the host:
@@ -194,31 +254,42 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
         const int n_need = __popcll(need);
         const bool any_have = (need != ~0ull);
 
-        if (!exhausted && n_need > 0 && (n_need >= REFILL_MIN || !any_have)) {
+        // A wave visits the queue when enough of its lanes are free, and once more when it leaves: rays that have ended since the last visit are
+        // written out there -- the ONE place in the kernel where a ray is stored (the pipeline instances' store path is a few thousand instructions).
+        const bool visit = !exhausted && n_need > 0 && (n_need >= REFILL_MIN || !any_have);
+        const bool leaving = !visit && !any_have;          // nothing held and nothing left to take
+        if (visit || leaving) {
+            if (pend) {
+                // (not under a divergent branch of its own in the step loop: that branch ran in one wave iteration out of nine for a single
+                // lane's ~40 instructions)
+                my_steps += (unsigned long long) s.steps;
+                io.store(idx, s, finish_status<T, USE_DEST>(s, c));
+                pend = false;
+            }
+            if (leaving) break;
 #if KR_OCC_STATS
             ++occ_refills; occ_refill_lanes += n_need;
 #endif
             // wave-aggregated dequeue: one atomic for all free lanes
             const int leader = __ffsll((long long) need) - 1;
             unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&counters[0], (unsigned long long) n_need);
-            base = __shfl(base, leader, 64);
-            if (base + (unsigned long long) n_need >= (unsigned long long) n) exhausted = true;
-            if (pend) {
-                // (stored here, with every lane that has finished since the last visit, rather than under its own divergent branch in the
-                // step loop: that branch ran in one wave iteration out of nine for a single lane's ~40 instructions)
-                my_steps += (unsigned long long) s.steps;
-                store_ray(&rays[idx], s, finish_status<T, USE_DEST>(s, c));
-                pend = false;
+            if (first_slot >= 0) {
+                // (HOG instances: this wave's first 64 slots are its own by position; the shared queue head counts from head_offset on)
+                base = (unsigned long long) first_slot;
+                first_slot = -1;
+            } else {
+                if (lane == leader) base = atomicAdd(&counters[0], (unsigned long long) n_need);
+                base = __shfl(base, leader, 64) + head_offset;
             }
+            if (base + (unsigned long long) n_need >= (unsigned long long) n) exhausted = true;
             if (!have) {
                 const long long slot = (long long) base + __popcll(need & (lane_bit - 1));
                 if (slot < n && !(mask && mask[slot] != (unsigned char) mask_want)) {
                     const long long mine = list ? (long long) list[slot] : slot;
-                    load_ray(&rays[mine], s);
+                    const long long handle = io.load(mine, s);
                     // skip rule of run_raytrace (raytracer.cpp:116-117)
                     if (s.steps0 >= 0 && s.steps0 < c.steplim) {
-                        idx = mine;
+                        idx = handle;
                         have = true;
                         ++my_traced;
                         s.steps = 0;
@@ -232,18 +303,15 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
                         s.carry_ok = false;
                         if (METHOD == KR_RK45) rk45_seed(s, c);
                         if (!loop_cond<T, USE_DEST>(s, c)) {
-                            // zero-iteration call: only the epilogue runs
-                            const int32_t out_steps = finish_status<T, USE_DEST>(s, c);
-                            store_ray(&rays[idx], s, out_steps);
+                            // zero-iteration call: only the epilogue runs (at the next visit)
                             have = false;
+                            pend = true;
                         }
                     }
                 }
             }
             continue;   // re-evaluate the ballots (skipped / zero-iteration rays leave lanes free)
         }
-
-        if (!any_have) break;   // nothing held and (exhausted or nothing needed): only reachable when exhausted
 
 #if KR_LONG_RAY_PRIO
         if (!HOG && (++prio_tick & 15) == 0)   // (a wave that owns its SIMD has nobody to take priority over; the thresholds are thousands of steps)
@@ -292,11 +360,6 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
             }
         }
     }
-    if (pend) {                                           // rays that ended after the wave's last visit to the queue
-        my_steps += (unsigned long long) s.steps;
-        store_ray(&rays[idx], s, finish_status<T, USE_DEST>(s, c));
-    }
-
     // per-wave totals -> global counters (4 atomics per wave, once)
     const unsigned long long w_traced = wave_sum<T>(my_traced);
     const unsigned long long w_steps = wave_sum<T>(my_steps);
@@ -324,13 +387,54 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
 }
 
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_HOG_ATTR
+__global__ void __attribute__((amdgpu_flat_work_group_size(block_of(HOG), block_of(HOG)))) KR_HOG_ATTR
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
              const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want)
 {
     if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
     int has_prio = 0;
-    trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(rays, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio);
+    if constexpr (HOG) {
+        constexpr int kWaves = kHogBlock / 64;
+        const long long g = (long long) blockIdx.x * kWaves + (threadIdx.x >> 6);
+        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(RecordIO<T>{rays}, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio, g * 64,
+                                                               (unsigned long long) gridDim.x * kWaves * 64);
+    } else {
+        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(RecordIO<T>{rays}, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio);
+    }
+}
+
+// The same persistent kernel with the emissivity pipeline's load and store paths (EmisPipeIO above): double precision, theta-limit overload.
+template <int METHOD, bool FAST, bool HOG, int REFILL_MIN>
+__global__ void __attribute__((amdgpu_flat_work_group_size(block_of(HOG), block_of(HOG)))) KR_HOG_ATTR
+trace_pipe_kernel(EmisPipeArgs args, long long n, TraceConsts<double> c, unsigned long long* __restrict__ counters,
+                  const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want)
+{
+    extern __shared__ double pipe_lds[];
+    if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
+    const int words = 5 * args.bins.nr + 1;
+    if (args.use_lds) {
+        for (int w = threadIdx.x; w < words; w += block_of(HOG)) pipe_lds[w] = 0;
+        __syncthreads();
+    }
+    double a_start = args.reverse_start ? -1 * args.src.spin : args.src.spin, V_start = args.V_start;
+    if (V_start == -1) {       // the orbital velocity at source ray 0, kept for every ray (raytracer.cpp:389-393)
+        const kr_ray_f64 r0 = pointsource_ray(args.src, args.n_grid, args.n_beta, 0);
+        V_start = keplerian_V<double>(a_start, r0.r, r0.theta, args.projradius_start != 0);
+    }
+    const EmisPipeIO io{&args, args.use_lds ? pipe_lds : args.hist, a_start, V_start, kr_log(args.bins.dr)};
+    int has_prio = 0;
+    if constexpr (HOG) {
+        constexpr int kWaves = kHogBlock / 64;
+        const long long g = (long long) blockIdx.x * kWaves + (threadIdx.x >> 6);
+        trace_body<double, METHOD, false, FAST, HOG, REFILL_MIN>(io, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio, g * 64, (unsigned long long) gridDim.x * kWaves * 64);
+    } else {
+        trace_body<double, METHOD, false, FAST, HOG, REFILL_MIN>(io, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio);
+    }
+    if (args.use_lds) {
+        __syncthreads();
+        for (int w = threadIdx.x; w < words; w += block_of(HOG))
+            if (pipe_lds[w] != 0) atomicAdd(&args.hist[w], pipe_lds[w]);
+    }
 }
 
 // ONE grid over MANY traces (kr_trace_batch_async_f64 when all traces of the batch use the same kernel instances).  Every wave serves
@@ -342,14 +446,22 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
 // profiles/r02_hw_queues.txt).  (A first version let each wave walk through all traces in turn: every wave then paid the tail of one
 // long ray PER TRACE, 2.9 s for the 18-point sweep instead of 0.6 s.)  Per-ray arithmetic is the single-trace kernel's: same bits.
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_HOG_ATTR
+__global__ void __attribute__((amdgpu_flat_work_group_size(block_of(HOG), block_of(HOG)))) KR_HOG_ATTR
 trace_multi_kernel(const TraceDesc<T>* __restrict__ descs, int n_desc, const int* __restrict__ wave_trace)
 {
     if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
     int has_prio = 0;
     const int ti = wave_trace ? wave_trace[blockIdx.x] : (int) (blockIdx.x % (unsigned) n_desc);
     const TraceDesc<T>* d = &descs[ti];                           // wave-uniform: scalar loads
-    trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(d->rays, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio);
+    if constexpr (HOG) {
+        // (HOG batches map workgroup -> trace by modulo: workgroup b is the (b / n_desc)-th of its trace's gridDim.x / n_desc workgroups)
+        constexpr int kWaves = kHogBlock / 64;
+        const long long g = (long long) (blockIdx.x / (unsigned) n_desc) * kWaves + (threadIdx.x >> 6);
+        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(RecordIO<T>{d->rays}, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio, g * 64,
+                                                               (unsigned long long) (gridDim.x / (unsigned) n_desc) * kWaves * 64);
+    } else {
+        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(RecordIO<T>{d->rays}, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio);
+    }
 }
 
 // ---- hybrid path: which rays must be integrated with the reference's exact arithmetic? ----------------------------
@@ -360,27 +472,21 @@ trace_multi_kernel(const TraceDesc<T>* __restrict__ descs, int n_desc, const int
 // strict path reproduces it; every other ray is insensitive to a few ulp per operation (tests/parity.py) and may
 // take the fast path.  In the lamp-post workloads the ill-conditioned rays are also the longest ones (they ride the
 // polar axis in MIN_STEP steps), which is why they get SIMDs of their own (HOG launch).
-__global__ void __launch_bounds__(kBlock)
-classify_kernel(const kr_ray_f64* __restrict__ rays, long long n, double a, unsigned char* __restrict__ strict_mask, int* __restrict__ list_strict,
-                unsigned long long* __restrict__ n_strict)
+KR_DEV bool ill_conditioned(double k, double h, double Q, double theta, double a)
 {
-    // one ray per work-item: the pass is a 4-field gather over 144-byte records, so it wants every load in flight at once
-    const long long i = blockIdx.x * (long long) kBlock + threadIdx.x;
-    if (i >= n) return;
-    const kr_ray_f64* ray = &rays[i];
-    bool strict = false;
-    if (ray->steps >= 0) {                       // unused slots (steps == -1) are skipped by either launch
-        const double k = ray->k, h = ray->h, Q = ray->Q, theta = ray->theta;
-        double sn, cs;
-        kr_sincos_f64(theta, sn, cs);
-        const double kac = k * a * cs;
-        const double hcs = h * cs / sn;
-        const double prod = (kac + hcs) * (kac - hcs);
-        const double sum = Q + prod;
-        strict = !(__builtin_fabs(sum) > 1e-9 * (__builtin_fabs(Q) + __builtin_fabs(prod))) || !(__builtin_fabs(h) >= 1e-13);
-    }
-    // wave-aggregated append; ill-conditioned rays are rare (a column / a row of the source grid), so are the atomics.
-    // mask: 0 = main launch, 1 = listed (strict side launch), 2 = ill-conditioned but the list is full (strict overflow launch)
+    double sn, cs;
+    kr_sincos_f64(theta, sn, cs);
+    const double kac = k * a * cs;
+    const double hcs = h * cs / sn;
+    const double prod = (kac + hcs) * (kac - hcs);
+    const double sum = Q + prod;
+    return !(__builtin_fabs(sum) > 1e-9 * (__builtin_fabs(Q) + __builtin_fabs(prod))) || !(__builtin_fabs(h) >= 1e-13);
+}
+
+// wave-aggregated append; ill-conditioned rays are rare (a column / a row of the source grid), so are the atomics.
+// mask: 0 = main launch, 1 = listed (strict side launch), 2 = ill-conditioned but the list is full (strict overflow launch)
+KR_DEV unsigned char classify_append(bool strict, long long i, int* __restrict__ list_strict, unsigned long long* __restrict__ n_strict)
+{
     const unsigned long long m = __ballot(strict);
     unsigned char mine = 0;
     if (m != 0) {
@@ -395,7 +501,33 @@ classify_kernel(const kr_ray_f64* __restrict__ rays, long long n, double a, unsi
             else mine = 2;
         }
     }
-    strict_mask[i] = mine;
+    return mine;
+}
+
+__global__ void __launch_bounds__(kBlock)
+classify_kernel(const kr_ray_f64* __restrict__ rays, long long n, double a, unsigned char* __restrict__ strict_mask, int* __restrict__ list_strict,
+                unsigned long long* __restrict__ n_strict)
+{
+    // one ray per work-item: the pass is a 4-field gather over 144-byte records, so it wants every load in flight at once
+    const long long i = blockIdx.x * (long long) kBlock + threadIdx.x;
+    if (i >= n) return;
+    const kr_ray_f64* ray = &rays[i];
+    bool strict = false;
+    if (ray->steps >= 0) strict = ill_conditioned(ray->k, ray->h, ray->Q, ray->theta, a);       // unused slots (steps == -1) are skipped by either launch
+    strict_mask[i] = classify_append(strict, i, list_strict, n_strict);
+}
+
+// the same for the emissivity pipeline: the ray's constants come from the source, not from memory
+__global__ void __launch_bounds__(kBlock)
+classify_pipe_kernel(EmisPipeArgs args, long long n, double a, unsigned char* __restrict__ strict_mask, int* __restrict__ list_strict,
+                     unsigned long long* __restrict__ n_strict)
+{
+    const long long i = blockIdx.x * (long long) kBlock + threadIdx.x;
+    if (i >= n) return;
+    const kr_ray_f64 ray = pointsource_ray(args.src, args.n_grid, args.n_beta, args.first + i * args.stride);
+    bool strict = false;
+    if (ray.steps >= 0) strict = ill_conditioned(ray.k, ray.h, ray.Q, ray.theta, a);
+    strict_mask[i] = classify_append(strict, i, list_strict, n_strict);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -634,6 +766,7 @@ struct ListArgs {
     const unsigned char* mask = nullptr;          // per-ray launch selector, or null
     int mask_want = 0;
     int fixed_grid = 0;                           // > 0: launch exactly this many workgroups
+    const EmisPipeArgs* pipe = nullptr;           // emissivity pipeline: rays are generated / reduced in the kernel (no records; `rays` is unused)
 };
 
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG = false>
@@ -647,7 +780,7 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     int blocks_per_cu = occ.load(std::memory_order_relaxed);
     if (blocks_per_cu == 0) {
         int v = 0;
-        KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, kTraceBlock, 0));
+        KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, block_of(HOG), 0));
         blocks_per_cu = v < 1 ? 1 : v;
         occ.store(blocks_per_cu, std::memory_order_relaxed);
     }
@@ -669,7 +802,17 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     const int64_t wanted = (n + kTraceBlock - 1) / kTraceBlock;
     int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
     if (la.fixed_grid > 0) grid = la.fixed_grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTraceBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.n_mode, la.mask, la.mask_want);
+    if constexpr (std::is_same<T, double>::value && !USE_DEST) {
+        if (la.pipe) {
+            const size_t lds = la.pipe->use_lds ? (size_t) (5 * la.pipe->bins.nr + 1) * sizeof(double) : 0;
+            hipLaunchKernelGGL((trace_pipe_kernel<METHOD, FAST, HOG, kRefill>), dim3(grid), dim3(block_of(HOG)), lds, stream, *la.pipe, (long long) n, c, counters, la.list,
+                               la.n_ptr, la.n_mode, la.mask, la.mask_want);
+            KR_HIP(hipGetLastError());
+            return KR_OK;
+        }
+    }
+    if (la.pipe) { set_error("kr_trace: the pipeline instances exist for the double-precision theta-limit overloads only"); return KR_EINVAL; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block_of(HOG)), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.n_mode, la.mask, la.mask_want);
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
@@ -697,7 +840,7 @@ int launch_multi(const TraceDesc<T>* d_descs, int n_desc, const int* d_wave_trac
 {
     constexpr int kRefill = KR_REFILL_MIN;
     auto kern = trace_multi_kernel<T, METHOD, USE_DEST, FAST, HOG, kRefill>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTraceBlock), 0, stream, d_descs, n_desc, d_wave_trace);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block_of(HOG)), 0, stream, d_descs, n_desc, d_wave_trace);
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
@@ -726,7 +869,7 @@ int launch_multi_f64(int integrator, bool dest, const TraceDesc<double>* d, int 
 // empty leave at once); a source made mostly of ill-conditioned rays (all rays in one meridional plane, say) overflows the
 // list, and the overflow -- mask value 2 -- is traced by a third, ordinary-occupancy strict launch that is a no-op otherwise
 // (its workgroups read the count and leave).
-int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream)
+int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream, const EmisPipeArgs* pipe = nullptr)
 {
     if (n > 0x7fffffff) { set_error("kr_trace: the split path indexes rays with 32 bits"); return KR_EINVAL; }
     {
@@ -736,7 +879,8 @@ int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wo
     unsigned long long* split_words = ws->counters + 3 * kCounters;     // [1] n_strict (zeroed by the caller's memset)
     const TraceConsts<double> c = make_consts<double>(p, steplim);
     const int cgrid = (int) ((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, ws->mask, ws->list, split_words + 1);
+    if (pipe) hipLaunchKernelGGL(classify_pipe_kernel, dim3(cgrid), dim3(kBlock), 0, stream, *pipe, (long long) n, p->spin, ws->mask, ws->list, split_words + 1);
+    else hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, ws->mask, ws->list, split_words + 1);
     KR_HIP(hipGetLastError());
     KR_HIP(hipEventRecord(ws->ev_classified, stream));
     hipStream_t caller = stream;
@@ -750,8 +894,9 @@ int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wo
     strict_la.list = ws->list;
     strict_la.n_ptr = split_words + 1;
     strict_la.n_mode = 1;
+    strict_la.pipe = pipe;
     const int64_t list_max = std::min<int64_t>(n, kListCap);
-    strict_la.fixed_grid = (int) std::max<int64_t>(1, std::min<int64_t>((list_max + kTraceBlock - 1) / kTraceBlock, (int64_t) (ws->cus / 2) * (4 / kWavesPerBlock)));
+    strict_la.fixed_grid = (int) std::max<int64_t>(1, std::min<int64_t>((list_max + kHogBlock - 1) / kHogBlock, (int64_t) (ws->cus / 2) * (256 / kHogBlock)));
     const int rc = launch_f64<false, true>(p, rays, list_max, c, ws->counters + kCounters, ws->cus, stream, 1, strict_la);
     if (rc != KR_OK) return rc;
     KR_HIP(hipEventRecord(ws->ev_strict1, stream));
@@ -760,7 +905,7 @@ int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wo
     return KR_OK;
 }
 
-int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream, bool fast_main)
+int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream, bool fast_main, const EmisPipeArgs* pipe = nullptr)
 {
     unsigned long long* split_words = ws->counters + 3 * kCounters;
     const TraceConsts<double> c = make_consts<double>(p, steplim);
@@ -771,6 +916,7 @@ int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wor
     ListArgs main_la;
     main_la.mask = ws->mask;
     main_la.mask_want = 0;
+    main_la.pipe = pipe;
     const int main_waves = mb ? mb : (fast_main && p->integrator == KR_EULER) ? 4 : 3;      // resident waves per SIMD of the main launch
     int rc = fast_main ? launch_f64<true, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, main_waves, main_la)
                        : launch_f64<false, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, main_waves, main_la);
@@ -784,6 +930,7 @@ int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wor
         rest_la.n_mode = 2;
         rest_la.mask = ws->mask;
         rest_la.mask_want = 2;
+        rest_la.pipe = pipe;
         rc = launch_f64<false, false>(p, rays, n, c, ws->counters + 2 * kCounters, ws->cus, ws->side_stream, mb, rest_la);
         if (rc != KR_OK) return rc;
     }
@@ -793,8 +940,10 @@ int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wor
 }
 
 template <typename T>
-int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned long long* counters, int cus, hipStream_t stream)
+int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned long long* counters, int cus, hipStream_t stream, const EmisPipeArgs* pipe = nullptr)
 {
+    ListArgs la;
+    la.pipe = pipe;
     using R = typename RayOf<T>::type;
     R* rays = (R*) d_rays;
     const TraceConsts<T> c = make_consts<T>(p, steplim);
@@ -803,30 +952,31 @@ int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned 
     if constexpr (std::is_same<T, double>::value) {
         if (p->flags & KR_FLAG_FAST_MATH) {
             switch (p->integrator) {
-                case KR_EULER: return launch<T, KR_EULER, false, true>(rays, n, c, counters, cus, stream, mb);
+                case KR_EULER: return launch<T, KR_EULER, false, true>(rays, n, c, counters, cus, stream, mb, la);
                 case KR_RK4:
-                    return dest ? launch<T, KR_RK4, true, true>(rays, n, c, counters, cus, stream, mb)
-                                : launch<T, KR_RK4, false, true>(rays, n, c, counters, cus, stream, mb);
+                    return dest ? launch<T, KR_RK4, true, true>(rays, n, c, counters, cus, stream, mb, la)
+                                : launch<T, KR_RK4, false, true>(rays, n, c, counters, cus, stream, mb, la);
                 default:
-                    return dest ? launch<T, KR_RK45, true, true>(rays, n, c, counters, cus, stream, mb)
-                                : launch<T, KR_RK45, false, true>(rays, n, c, counters, cus, stream, mb);
+                    return dest ? launch<T, KR_RK45, true, true>(rays, n, c, counters, cus, stream, mb, la)
+                                : launch<T, KR_RK45, false, true>(rays, n, c, counters, cus, stream, mb, la);
             }
         }
     }
     switch (p->integrator) {
-        case KR_EULER: return launch<T, KR_EULER, false, false>(rays, n, c, counters, cus, stream, mb);
+        case KR_EULER: return launch<T, KR_EULER, false, false>(rays, n, c, counters, cus, stream, mb, la);
         case KR_RK4:
-            return dest ? launch<T, KR_RK4, true, false>(rays, n, c, counters, cus, stream, mb)
-                        : launch<T, KR_RK4, false, false>(rays, n, c, counters, cus, stream, mb);
+            return dest ? launch<T, KR_RK4, true, false>(rays, n, c, counters, cus, stream, mb, la)
+                        : launch<T, KR_RK4, false, false>(rays, n, c, counters, cus, stream, mb, la);
         default:
-            return dest ? launch<T, KR_RK45, true, false>(rays, n, c, counters, cus, stream, mb)
-                        : launch<T, KR_RK45, false, false>(rays, n, c, counters, cus, stream, mb);
+            return dest ? launch<T, KR_RK45, true, false>(rays, n, c, counters, cus, stream, mb, la)
+                        : launch<T, KR_RK45, false, false>(rays, n, c, counters, cus, stream, mb, la);
     }
 }
 
-int validate(const kr_params* p, void* d_rays, int64_t n)
+int validate(const kr_params* p, void* d_rays, int64_t n, bool rays_needed = true)
 {
-    if (!p || (n > 0 && !d_rays) || n < 0) { set_error("kr_trace: null argument or negative n"); return KR_EINVAL; }
+    if (p && n > 0 && !d_rays && rays_needed) { set_error("kr_trace: null argument or negative n"); return KR_EINVAL; }
+    if (!p || n < 0) { set_error("kr_trace: null argument or negative n"); return KR_EINVAL; }
     if (p->integrator < KR_EULER || p->integrator > KR_RK45) { set_error("kr_trace: unknown integrator"); return KR_EINVAL; }
     if (p->stop_kind < KR_STOP_THETA || p->stop_kind > KR_STOP_FLATPLANE) { set_error("kr_trace: unknown stop_kind"); return KR_EINVAL; }
     if (p->stop_kind != KR_STOP_THETA && p->integrator == KR_EULER) {
@@ -851,11 +1001,12 @@ struct Pending {
     bool f32 = false, hybrid = false, split = false;
     int steplim = 0;
     Workspace* ws = nullptr;
+    const EmisPipeArgs* pipe = nullptr;       // emissivity pipeline (trace_pipeline_emis): no ray records
 };
 
 int trace_front(Pending& t, bool batch)
 {
-    int rc = validate(t.p, t.d_rays, t.n);
+    int rc = validate(t.p, t.d_rays, t.n, t.pipe == nullptr);
     if (rc != KR_OK) return rc;
     if (t.n == 0) return KR_OK;
     // effective_steplim, raytracer.cpp:80
@@ -882,7 +1033,7 @@ int trace_front(Pending& t, bool batch)
             auto it = g_strict_streams[ws->device].find(t.stream);
             if (it != g_strict_streams[ws->device].end()) ws->strict_stream = it->second;
         }
-        return split_front(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream);
+        return split_front(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream, t.pipe);
     }
     return KR_OK;
 }
@@ -892,8 +1043,8 @@ int trace_back(Pending& t)
     if (t.n == 0 || !t.ws) return KR_OK;
     Workspace* ws = t.ws;
     int r = t.f32 ? dispatch<float>(t.p, t.d_rays, t.n, t.steplim, ws->counters, ws->cus, t.stream)
-                  : t.split ? split_back(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream, t.hybrid)
-                            : dispatch<double>(t.p, t.d_rays, t.n, t.steplim, ws->counters, ws->cus, t.stream);
+                  : t.split ? split_back(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream, t.hybrid, t.pipe)
+                            : dispatch<double>(t.p, t.d_rays, t.n, t.steplim, ws->counters, ws->cus, t.stream, t.pipe);
     if (r != KR_OK) return r;
     KR_HIP(hipEventRecord(ws->ev1, t.stream));
     KR_HIP(hipMemcpyAsync(ws->h_counters, ws->counters, kCounterBlocks * kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, t.stream));
@@ -1027,8 +1178,9 @@ int merged_batch(std::vector<Pending>& ts, bool hybrid)
     // side launch (wave -> trace by modulo): as many waves per trace as its list could need, but no more than fit on the chip at once
     // in total (1024 SIMDs; at least 4 per trace) -- a wave refills from its trace's list, so fewer waves only mean more rays per wave,
     // whereas thousands of exclusive single-wave workgroups that find nothing to do still have to be placed one by one
-    const int64_t hog_per_trace = std::max<int64_t>(4, std::min<int64_t>(hog_max, (4 * (int64_t) w0->cus) / count));
-    rc = launch_multi_f64<false, true>(p0->integrator, dest, d, count, nullptr, (int) (hog_per_trace * count), primary);
+    const int64_t hog_per_trace = std::max<int64_t>(4, std::min<int64_t>(hog_max, (4 * (int64_t) w0->cus) / count));            // waves
+    const int64_t hog_wgs_per_trace = (hog_per_trace * 64 + kHogBlock - 1) / kHogBlock;                                          // workgroups
+    rc = launch_multi_f64<false, true>(p0->integrator, dest, d, count, nullptr, (int) (hog_wgs_per_trace * count), primary);
     if (rc != KR_OK) return rc;
     for (auto& t : ts) KR_HIP(hipEventRecord(t.ws->ev_strict1, primary));
     KR_HIP(hipStreamWaitEvent(side, w0->ev_classified, 0));
@@ -1188,6 +1340,26 @@ int trace_shutdown()
     if (have_dev) (void) hipSetDevice(keep);
     (void) hipGetLastError();
     return KR_OK;
+}
+
+// The emissivity pipeline (kr_emissivity_pipeline_dev_f64): source -> redshift_start -> run_raytrace -> redshift -> radial histogram as ONE trace
+// (classification + side launch + main launch like any other; EmisPipeIO), the rays living in registers from birth to bin.
+int trace_pipeline_emis(const kr_params* p, const EmisPipeArgs* args, int64_t n, hipStream_t stream, kr_stats* stats)
+{
+    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->rays_total = n; }
+    if (!args || !args->hist) { set_error("kr_emissivity_pipeline: null argument"); return KR_EINVAL; }
+    if (p && (p->stop_kind != KR_STOP_THETA)) { set_error("kr_emissivity_pipeline: theta-limit overload only"); return KR_EINVAL; }
+    Pending t;
+    t.p = p; t.d_rays = nullptr; t.n = n; t.stream = stream; t.f32 = false; t.pipe = args;
+    int rc = trace_front(t, false);
+    if (rc == KR_OK) rc = trace_back(t);
+    if (rc != KR_OK) { abandon(t); return rc; }
+    void* ticket = nullptr;
+    hand_over(t, &ticket);
+    if (!stats) { trace_release(ticket); return KR_OK; }
+    const int rc2 = trace_wait(ticket, stats);
+    stats->rays_total = n;
+    return rc2;
 }
 
 int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, kr_stats* stats, bool f32)

@@ -69,7 +69,9 @@ def cases():
         })
     c["ps_h10"] = dict(
         source=_ps([0.0, 10.0, 1e-3, 1.5707], 0.0, 0.1, 0.1), start=(0.0, 0, 0), post=(-1.0, 0, 0),
-        runs={"euler": _params(capi.EULER), "rk4": _params(capi.RK4), "rk45": _params(capi.RK45)})
+        runs={"euler": _params(capi.EULER), "rk4": _params(capi.RK4), "rk45": _params(capi.RK45),
+              # BASELINE configs[2] at h = 10: both ends of the tolerance sweep of src/tests/emissivity_rk45_tol_sweep.py:38
+              "rk45_tol1e-6": _params(capi.RK45, rk45_tol=1e-6), "rk45_tol1e-10": _params(capi.RK45, rk45_tol=1e-10)})
     c["ps_kep"] = dict(
         source=_ps([0.0, 5.0, 1e-3, 0.0], kep_velocity(5.0), 0.2, 0.2, full_range=False),
         start=(kep_velocity(5.0), 0, 0), post=(-1.0, 0, 0),
