@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iterator>
@@ -139,46 +140,56 @@ template <typename T> struct RecordIO {
     KR_DEV void store(long long i, const Lane<T>& s, int32_t out_steps) const { store_ray(&rays[i], s, out_steps); }
 };
 
-// EmissivityPipe (kr_emissivity_pipeline_dev_f64): NO ray record exists in memory.  A lane that takes slot i off the queue
-// builds PointSource ray first + i stride in registers (pointsource.cpp:30-64 + calculate_constants, raytracer.cpp:625-676) and, when the ray has
-// ended, redshifts it (redshift_start's `emit` is recomputed from the source ray -- a few hundred instructions against ~500 steps of ~400 --
-// rather than carried through the step loop in two more registers; raytracer.cpp:342-417, :420-553) and adds it to the workgroup's copy of the
-// radial histogram in LDS (emissivity.cpp:96-126), which is flushed with one global atomic per non-empty word when the wave leaves.  The
-// per-ray functions are the ones the streaming kernels of kr_post.hip use (kr_post_device.hpp): same bits per ray; the histogram's sums differ
-// from theirs only in the order of addition.
-// The two ends are inlined ONCE each: trace_body loads a ray in one place and stores one in one place.  (As out-of-line calls they left the
-// register allocator with half the file across the call sites and the step loop full of spills: main launch 65 -> 85 ms.  Inlined at the three
-// store sites the loop used to have, every pipeline instance was 110-150 KB of code against a 64-KB instruction cache.)
-// (`emit`, redshift_start's result, depends on the ray only through k, h, Q -- which the lane keeps -- and the two INITIAL direction signs: those
-// ride in the top bits of the lane's 64-bit slot index (tag), so the store path need not build the source ray a second time.)
-struct EmisPipeIO {
-    const EmisPipeArgs* a;
-    double* acc;                // LDS copy of the histogram, or a->hist
-    double a_start, V_start;    // redshift_start's effective spin and (resolved) velocity
-    double log_dr;              // log of the bin ratio, from the device's log like the streaming reducer's
-    static constexpr long long kTagR = 1ll << 62, kTagTheta = 1ll << 61, kIndexMask = kTagTheta - 1;
-    KR_DEV long long load(long long i, Lane<double>& s) const
-    {
-        const kr_ray_f64 r = pointsource_ray(a->src, a->n_grid, a->n_beta, a->first + i * a->stride);
-        s.t = r.t; s.r = r.r; s.theta = r.theta; s.phi = r.phi;
-        s.pt = 0; s.pr = 0; s.ptheta = 0; s.pphi = 0;
-        s.k = r.k; s.h = r.h; s.Q = r.Q;
-        s.steps0 = r.steps; s.status = r.status; s.rdot_sign = r.rdot_sign; s.thetadot_sign = r.thetadot_sign;
-        s.rdot_flips = r.rdot_flips; s.eq_cross = r.equatorial_crossings;
-        return i | (r.rdot_sign < 0 ? kTagR : 0) | (r.thetadot_sign < 0 ? kTagTheta : 0);
-    }
-    KR_DEV void store(long long tagged, const Lane<double>& s, int32_t out_steps) const
-    {
-        kr_ray_f64 v;
-        v.r = a->src.pos[1]; v.theta = a->src.pos[2];              // where every ray of the source starts
-        v.k = s.k; v.h = s.h; v.Q = s.Q;
-        v.rdot_sign = (tagged & kTagR) ? -1 : 1; v.thetadot_sign = (tagged & kTagTheta) ? -1 : 1;
-        v.emit = emit_value(v, a->src.spin, a_start, V_start, a->reverse_start);
-        v.r = s.r; v.theta = s.theta; v.rdot_sign = s.rdot_sign; v.thetadot_sign = s.thetadot_sign;
-        const double g = redshift_value(v, a->spin, a->V, a->reverse, a->projradius, a->motion);
-        emissivity_accumulate(acc, a->bins, log_dr, out_steps, s.r, s.theta, g, s.t);
-    }
+// ---- the emissivity pipeline inside the trace kernel (kr_emissivity_pipeline_dev_f64): NO ray record exists in memory ----
+// Source rays are built in the kernel (pointsource.cpp:30-64 + calculate_constants, raytracer.cpp:625-676), finished rays are redshifted
+// (raytracer.cpp:342-417, :420-553) and added to the workgroup's copy of the radial histogram in LDS (emissivity.cpp:96-126), flushed with one
+// global atomic per non-empty word when the wave leaves.  The per-ray functions are the ones the streaming kernels of kr_post.hip use
+// (kr_post_device.hpp): same bits per ray; the sums differ from theirs only in the order of addition.
+// Both ends are a few thousand instructions per ray, and a wave visits the work queue when FOUR of its lanes are free: run by the lanes that
+// need them they execute at 6-12 % lane occupancy and cost more than a third of the stepping itself (first version: main launch 65 -> 83 ms).
+// So both ends run on FULL waves and meet the step loop through two small rings in LDS (one wave per workgroup: no barriers):
+//   in-ring   a visit that finds the ring short claims 64 queue slots and ALL 64 lanes build one source ray each; what a ray IS -- k, h, Q and
+//             its two initial direction signs; every ray of a PointSource starts at the same event -- is pushed (valid rays only); the free
+//             lanes pop;
+//   out-ring  lanes whose ray has ended push r, theta, t, k, h, Q, the signs and the step count; whenever 64 are waiting (and when the wave
+//             leaves) all lanes take one each through redshift_start's `emit`, redshift and the histogram.
+// Layout of a workgroup's (= a wave's) dynamic LDS, in doubles from pipe_lds: [histogram: hist_words][in_k, in_h, in_Q: 64 each][out_r, out_theta,
+// out_t, out_k, out_h, out_Q: 128 each] then ints [in_meta: 64][out_steps: 128][out_meta: 128].  Addressed as pipe_lds[offset + i] throughout, so
+// that every access is a ds_read / ds_write at a constant offset from ONE base register (a struct of pointers cost the step loop 24 registers and
+// turned the accesses into flat ones: main launch 265 ms).
+//   in_meta: bit 0 rdot_sign < 0, bit 1 thetadot_sign < 0;   out_meta: bits 0-1 the initial signs, bits 2-3 the final ones
+extern __shared__ double pipe_lds[];
+struct PipeRings {
+    static constexpr int kIn = 64, kOut = 128;
+    static constexpr int kInK = 0, kInH = kIn, kInQ = 2 * kIn, kOutR = 3 * kIn, kOutTheta = kOutR + kOut, kOutT = kOutR + 2 * kOut, kOutK = kOutR + 3 * kOut,
+                         kOutH = kOutR + 4 * kOut, kOutQ = kOutR + 5 * kOut, kDoubles = kOutR + 6 * kOut;
+    static constexpr int kInMeta = 0, kOutSteps = kIn, kOutMeta = kIn + kOut, kInts = kIn + 2 * kOut;
+    static size_t bytes(int hist_words) { return (size_t) (hist_words + kDoubles) * 8 + (size_t) kInts * 4; }
 };
+
+// The two ends are OUT-OF-LINE functions, called from a visit that keeps nothing of the step loop's state in registers (it is parked in private
+// memory, trace_body_pipe): their register appetite -- thousands of instructions each -- is then their own.  Inlined, they shared one allocation
+// with the step loop and left it with ~40 spill accesses per step (SQ_INSTS_VMEM 3.4e9 per launch against 3.4e7: main launch 65 -> 240-265 ms).
+struct PipeSourceRay { double k, h, Q; int meta, steps; };
+__device__ __attribute__((noinline)) PipeSourceRay pipe_source(const EmisPipeArgs* a, long long ix)
+{
+    const kr_ray_f64 ray = pointsource_ray(a->src, a->n_grid, a->n_beta, ix);
+    return PipeSourceRay{ray.k, ray.h, ray.Q, (ray.rdot_sign < 0 ? 1 : 0) | (ray.thetadot_sign < 0 ? 2 : 0), ray.steps};
+}
+
+// one finished ray through redshift_start's emit, redshift() and the histogram
+__device__ __attribute__((noinline)) void pipe_sink(const EmisPipeArgs& a, double* hist, double a_start, double V_start, double log_dr, double r, double theta, double t, double k, double h,
+                      double Q, int meta, int out_steps)
+{
+    kr_ray_f64 v;
+    v.r = a.src.pos[1]; v.theta = a.src.pos[2];              // where every ray of the source starts
+    v.k = k; v.h = h; v.Q = Q;
+    v.rdot_sign = (meta & 1) ? -1 : 1; v.thetadot_sign = (meta & 2) ? -1 : 1;
+    v.emit = emit_value(v, a.src.spin, a_start, V_start, a.reverse_start);
+    v.r = r; v.theta = theta; v.rdot_sign = (meta & 4) ? -1 : 1; v.thetadot_sign = (meta & 8) ? -1 : 1;
+    const double g = redshift_value(v, a.spin, a.V, a.reverse, a.projradius, a.motion);
+    emissivity_accumulate(hist, a.bins, log_dr, out_steps, r, theta, g, t);
+}
 
 template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 {
@@ -403,38 +414,306 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     }
 }
 
-// The same persistent kernel with the emissivity pipeline's load and store paths (EmisPipeIO above): double precision, theta-limit overload.
-template <int METHOD, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(block_of(HOG), block_of(HOG)))) KR_HOG_ATTR
-trace_pipe_kernel(EmisPipeArgs args, long long n, TraceConsts<double> c, unsigned long long* __restrict__ counters,
-                  const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want)
+// The persistent loop of trace_body with the emissivity pipeline's two rings at its queue visits (double precision, theta-limit overload).
+// The WHOLE visit is one out-of-line function working on memory: the lane's state parked in private memory (PipeParked) and the wave's pipeline
+// state (PipeCtx: the two ring fills, the queue, copies of the arguments).  The step loop around it then carries strictly less than the record
+// kernel's does -- the visit's scalars had pushed the loop's hoisted constants out of the scalar file into a spill register and from there the
+// polynomial constants into scratch: ~11 scratch accesses and ~80 extra vector instructions PER STEP (main launch 102 ms against 64).
+struct PipeParked { Lane<double> s; unsigned long long my_steps, my_traced; int meta0; bool have, pend; };
+struct PipeCtx {
+    EmisPipeArgs a;
+    TraceConsts<double> c;
+    double* hist;                  // the wave's histogram (LDS) or the global one
+    double* rings;                 // the rings' doubles; their ints follow at rings + PipeRings::kDoubles
+    double a_start, V_start, log_dr;
+    long long n, first_slot;
+    unsigned long long head_offset;
+    unsigned long long* counters;
+    const int* list;
+    const unsigned char* mask;
+    int mask_want, in_count, out_count;
+    bool exhausted;
+};
+KR_DEV double& ring_d(const PipeCtx* x, int field, int i) { return x->rings[field + i]; }
+KR_DEV int& ring_i(const PipeCtx* x, int field, int i) { return reinterpret_cast<int*>(x->rings + PipeRings::kDoubles)[field + i]; }
+
+// returns "dry": the queue is exhausted and the in-ring empty (no further visit can hand out a ray)
+// (one instance per kernel instance -- FAST and HOG change nothing in it -- so that each inherits ITS kernel's register budget: shared between a
+// 512-register HOG kernel and a 168-register main kernel it took 194 and pushed the main kernel to 2 waves per SIMD)
+template <int METHOD, bool FAST, bool HOG>
+__device__ __attribute__((noinline)) bool pipe_visit(PipeParked* pk, PipeCtx* x, bool leaving)
 {
-    extern __shared__ double pipe_lds[];
-    if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
+    using T = double;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lanes_below = (1ull << lane) - 1;
+    Lane<T>& s = pk->s;
+    const unsigned long long need = __ballot(!pk->have);
+    const int n_need = __popcll(need);
+    int in_count = x->in_count, out_count = x->out_count;
+    // (1) rays that have ended since the last visit -> out-ring
+    const unsigned long long pm = __ballot(pk->pend);
+    if (pm != 0) {
+        if (pk->pend) {
+            const int e = out_count + __popcll(pm & lanes_below);
+            pk->my_steps += (unsigned long long) s.steps;
+            ring_i(x, PipeRings::kOutSteps, e) = finish_status<T, false>(s, x->c);
+            ring_d(x, PipeRings::kOutR, e) = s.r; ring_d(x, PipeRings::kOutTheta, e) = s.theta; ring_d(x, PipeRings::kOutT, e) = s.t;
+            ring_d(x, PipeRings::kOutK, e) = s.k; ring_d(x, PipeRings::kOutH, e) = s.h; ring_d(x, PipeRings::kOutQ, e) = s.Q;
+            ring_i(x, PipeRings::kOutMeta, e) = pk->meta0 | (s.rdot_sign < 0 ? 4 : 0) | (s.thetadot_sign < 0 ? 8 : 0);
+            pk->pend = false;
+        }
+        out_count += __popcll(pm);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (other lanes read these entries: LDS writes before the reads below)
+        __builtin_amdgcn_wave_barrier();
+    }
+    // (2) the sink, on full waves: 64 waiting rays at a time (whatever is left when the wave leaves)
+    while (out_count >= 64 || (leaving && out_count > 0)) {
+        const int m = out_count < 64 ? out_count : 64;
+        const int e = out_count - m + lane;
+        if (lane < m)
+            pipe_sink(x->a, x->hist, x->a_start, x->V_start, x->log_dr, ring_d(x, PipeRings::kOutR, e), ring_d(x, PipeRings::kOutTheta, e), ring_d(x, PipeRings::kOutT, e),
+                      ring_d(x, PipeRings::kOutK, e), ring_d(x, PipeRings::kOutH, e), ring_d(x, PipeRings::kOutQ, e), ring_i(x, PipeRings::kOutMeta, e),
+                      ring_i(x, PipeRings::kOutSteps, e));
+        out_count -= m;
+    }
+    // (3) free lanes take rays from the in-ring; when it runs dry, ALL lanes build the next 64 queue slots' rays into it
+    bool exhausted = x->exhausted;
+    int wanted = leaving ? 0 : n_need;
+    while (wanted > 0) {
+        const int take = wanted < in_count ? wanted : in_count;
+        if (take > 0) {
+            const int rank = __popcll(need & lanes_below) - (n_need - wanted);       // this free lane's turn among those still waiting
+            if (!pk->have && rank >= 0 && rank < take) {
+                const int e = in_count - 1 - rank;
+                s.t = x->a.src.pos[0]; s.r = x->a.src.pos[1]; s.theta = x->a.src.pos[2]; s.phi = x->a.src.pos[3];
+                s.pt = 0; s.pr = 0; s.ptheta = 0; s.pphi = 0;
+                s.k = ring_d(x, PipeRings::kInK, e); s.h = ring_d(x, PipeRings::kInH, e); s.Q = ring_d(x, PipeRings::kInQ, e);
+                const int meta0 = ring_i(x, PipeRings::kInMeta, e);
+                pk->meta0 = meta0;
+                s.rdot_sign = (meta0 & 1) ? -1 : 1; s.thetadot_sign = (meta0 & 2) ? -1 : 1;
+                s.steps0 = 0; s.status = 0; s.rdot_flips = 0; s.eq_cross = 0;
+                pk->have = true;
+                ++pk->my_traced;
+                s.steps = 0;
+                s.r_was_positive = false;
+                s.theta_was_positive = true;
+                s.in_retry = false;
+                s.creep_m = 0;
+                s.creep_run = 0;
+                s.creep_mode = false;
+                s.fsal_valid = false;
+                s.carry_ok = false;
+                if (METHOD == KR_RK45) rk45_seed(s, x->c);
+                if (!loop_cond<T, false>(s, x->c)) { pk->have = false; pk->pend = true; }      // zero-iteration call: only the epilogue runs (at the next visit)
+            }
+            in_count -= take;
+            wanted -= take;
+        }
+        if (wanted == 0 || exhausted) break;
+        // the ring is empty here: claim 64 slots, one source ray per lane
+        unsigned long long base = 0;
+        if (x->first_slot >= 0) {
+            base = (unsigned long long) x->first_slot;
+            x->first_slot = -1;
+        } else {
+            if (lane == 0) base = atomicAdd(&x->counters[0], 64ull);
+            base = __shfl(base, 0, 64) + x->head_offset;
+        }
+        if (base + 64ull >= (unsigned long long) x->n) exhausted = true;
+        const long long slot = (long long) base + lane;
+        bool valid = slot < x->n && !(x->mask && x->mask[slot] != (unsigned char) x->mask_want);
+        PipeSourceRay ray{0, 0, 0, 0, -1};
+        if (valid) {
+            const long long mine = x->list ? (long long) x->list[slot] : slot;
+            ray = pipe_source(&x->a, x->a.first + mine * x->a.stride);
+        }
+        valid = valid && ray.steps >= 0 && ray.steps < x->c.steplim;                  // skip rule of run_raytrace (raytracer.cpp:116-117)
+        const unsigned long long vm = __ballot(valid);
+        if (valid) {
+            const int e = in_count + __popcll(vm & lanes_below);
+            ring_d(x, PipeRings::kInK, e) = ray.k; ring_d(x, PipeRings::kInH, e) = ray.h; ring_d(x, PipeRings::kInQ, e) = ray.Q;
+            ring_i(x, PipeRings::kInMeta, e) = ray.meta;
+        }
+        in_count += __popcll(vm);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    x->in_count = in_count; x->out_count = out_count; x->exhausted = exhausted;
+    return exhausted && in_count == 0;
+}
+
+template <int METHOD, bool FAST, bool HOG, int REFILL_MIN>
+KR_DEV void trace_body_pipe(PipeCtx* x, const TraceConsts<double>& c, unsigned long long* __restrict__ counters, int& has_prio)
+{
+    using T = double;
+    const int lane = threadIdx.x & 63;
+    Lane<T> s;
+    int meta0 = 0;              // the ray's initial direction signs (pipe_sink needs them for `emit`)
+    bool have = false, pend = false;
+    bool dry = false;           // wave-uniform: queue exhausted and in-ring empty
+    unsigned long long my_steps = 0, my_traced = 0;
+    uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
+    PipeParked pk;
+#if KR_OCC_STATS
+    unsigned long long occ_iters = 0, occ_tail_iters = 0, occ_tail_steps = 0, occ_refills = 0, occ_refill_lanes = 0;
+#endif
+#if KR_LONG_RAY_PRIO
+    unsigned prio_tick = 0;
+#endif
+    for (;;) {
+        const unsigned long long need = __ballot(!have);
+        const int n_need = __popcll(need);
+        const bool any_have = (need != ~0ull);
+        const bool visit = n_need > 0 && (n_need >= REFILL_MIN || !any_have) && !dry;
+        const bool leaving = !visit && !any_have;
+        if (visit || leaving) {
+#if KR_OCC_STATS
+            ++occ_refills; occ_refill_lanes += n_need;
+#endif
+            // ~45 stores and loads per visit, once per ~60 wave steps
+            pk.s = s; pk.meta0 = meta0; pk.have = have; pk.pend = pend; pk.my_steps = my_steps; pk.my_traced = my_traced;
+            dry = __any(pipe_visit<METHOD, FAST, HOG>(&pk, x, leaving));
+            s = pk.s; meta0 = pk.meta0; have = pk.have; pend = pk.pend; my_steps = pk.my_steps; my_traced = pk.my_traced;
+            if (leaving) break;
+            continue;
+        }
+
+#if KR_LONG_RAY_PRIO
+        if (!HOG && (++prio_tick & 15) == 0) {      // (see trace_body)
+            const int32_t st = have ? s.steps : 0;
+            const int want_prio = __any(st > 8 * KR_LONG_RAY_STEPS) ? 3 : __any(st > 3 * KR_LONG_RAY_STEPS) ? 2 : __any(st > KR_LONG_RAY_STEPS) ? 1 : 0;
+            if (want_prio != has_prio) {
+                has_prio = want_prio;
+                switch (want_prio) {
+                    case 3: __builtin_amdgcn_s_setprio(3); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    default: __builtin_amdgcn_s_setprio(0); break;
+                }
+            }
+        }
+#endif
+        int replay_batch = 1;
+        if constexpr (METHOD == KR_RK45) {
+            if (!__any(have && !s.creep_mode)) replay_batch = 16;
+        }
+#if KR_OCC_STATS
+        ++occ_iters;
+        if (dry) { ++occ_tail_iters; occ_tail_steps += have ? 1 : 0; }
+#endif
+        if (have) {
+            bool fin;
+            if (METHOD == KR_EULER) fin = step_fixed<T, false, false, FAST>(s, c);
+            else if (METHOD == KR_RK4) fin = step_fixed<T, true, false, FAST>(s, c);
+            else fin = step_rk45<T, false, FAST>(s, c, my_attempts, my_rejects, my_stationary, my_creep, replay_batch);
+            if (fin) { have = false; pend = true; }
+        }
+    }
+
+    const unsigned long long w_traced = wave_sum<T>(my_traced);
+    const unsigned long long w_steps = wave_sum<T>(my_steps);
+    const unsigned long long w_att = wave_sum<T>((unsigned long long) my_attempts);
+    const unsigned long long w_rej = wave_sum<T>((unsigned long long) my_rejects);
+    const unsigned long long w_sta = wave_sum<T>((unsigned long long) my_stationary);
+    const unsigned long long w_creep = wave_sum<T>((unsigned long long) my_creep);
+#if KR_OCC_STATS
+    {
+        const unsigned long long w_tail_steps = wave_sum<T>(occ_tail_steps);
+        if (lane == 0) {
+            atomicAdd(&counters[7], occ_iters); atomicAdd(&counters[8], occ_tail_iters); atomicAdd(&counters[9], w_tail_steps);
+            atomicAdd(&counters[10], occ_refills); atomicAdd(&counters[11], occ_refill_lanes);
+        }
+    }
+#endif
+    if (lane == 0) {
+        if (w_sta) atomicAdd(&counters[5], w_sta);
+        if (w_creep) atomicAdd(&counters[6], w_creep);
+        if (w_traced) atomicAdd(&counters[1], w_traced);
+        if (w_steps) atomicAdd(&counters[2], w_steps);
+        if (w_att) atomicAdd(&counters[3], w_att);
+        if (w_rej) atomicAdd(&counters[4], w_rej);
+    }
+}
+
+// The wave's pipeline state is set up, and its histogram flushed, out of line as well, and pipe_begin reads the kernel's arguments through the
+// kernarg segment pointer (handed to it) rather than through references: nothing of them but the trace constants stays in scalar registers across the step loop,
+// and no argument's address is taken (a kernel argument whose address escapes is copied to private memory and read from THERE ever after: the
+// trace constants would move from scalar registers into 60 vector registers).
+struct PipeKernArgs {
+    EmisPipeArgs args;
+    long long n;
+    TraceConsts<double> c;
+    unsigned long long* counters;
+    const int* list;
+    const unsigned long long* n_ptr;
+    const unsigned char* mask;
+    int n_mode, mask_want;
+};
+
+template <int METHOD, bool FAST, bool HOG>
+__device__ __attribute__((noinline)) void pipe_begin(PipeCtx* x, const PipeKernArgs* ka, double* lds, long long first_slot, unsigned long long head_offset)
+{
+    const EmisPipeArgs& args = ka->args;
     const int words = 5 * args.bins.nr + 1;
-    if (args.use_lds) {
-        for (int w = threadIdx.x; w < words; w += block_of(HOG)) pipe_lds[w] = 0;
-        __syncthreads();
-    }
-    double a_start = args.reverse_start ? -1 * args.src.spin : args.src.spin, V_start = args.V_start;
-    if (V_start == -1) {       // the orbital velocity at source ray 0, kept for every ray (raytracer.cpp:389-393)
+    const int lds_words = args.use_lds ? words : 0;           // the rings follow the histogram
+    for (int w = threadIdx.x; w < lds_words; w += 64) lds[w] = 0;
+    x->a = args;
+    x->c = ka->c;
+    x->hist = args.use_lds ? lds : args.hist;
+    x->rings = lds + lds_words;
+    x->a_start = args.reverse_start ? -1 * args.src.spin : args.src.spin;
+    x->V_start = args.V_start;
+    if (x->V_start == -1) {       // the orbital velocity at source ray 0, kept for every ray (raytracer.cpp:389-393)
         const kr_ray_f64 r0 = pointsource_ray(args.src, args.n_grid, args.n_beta, 0);
-        V_start = keplerian_V<double>(a_start, r0.r, r0.theta, args.projradius_start != 0);
+        x->V_start = keplerian_V<double>(x->a_start, r0.r, r0.theta, args.projradius_start != 0);
     }
-    const EmisPipeIO io{&args, args.use_lds ? pipe_lds : args.hist, a_start, V_start, kr_log(args.bins.dr)};
+    x->log_dr = kr_log(args.bins.dr);
+    long long n = ka->n;
+    if (ka->n_ptr) {
+        const long long m = (long long) *ka->n_ptr;
+        n = (ka->n_mode == 1) ? (m < n ? m : n) : (m > (long long) kListCap ? n : 0);
+    }
+    x->n = n;
+    x->first_slot = first_slot;
+    x->head_offset = head_offset;
+    x->counters = ka->counters; x->list = ka->list; x->mask = ka->mask; x->mask_want = ka->mask_want;
+    x->in_count = 0; x->out_count = 0; x->exhausted = false;
+}
+
+template <int METHOD, bool FAST, bool HOG>
+__device__ __attribute__((noinline)) void pipe_end(PipeCtx* x)
+{
+    if (!x->a.use_lds) return;
+    const int words = 5 * x->a.bins.nr + 1;
+    const double* lds = x->hist;
+    for (int w = threadIdx.x; w < words; w += 64)
+        if (lds[w] != 0) atomicAdd(&x->a.hist[w], lds[w]);
+}
+
+template <int METHOD, bool FAST, bool HOG, int REFILL_MIN>
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64))) KR_HOG_ATTR
+trace_pipe_kernel(PipeKernArgs ka)
+{
+    if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
+    PipeCtx x;
+    // (the LDS -> generic cast is made here, on the scalar unit: as a vector operation -- in a callee, or feeding a call's argument registers
+    // directly -- this compiler emits an illegal compare against src_shared_base)
+    unsigned long long lds_bits = (unsigned long long) (uintptr_t) static_cast<double*>(pipe_lds);
+    asm volatile("" : "+s"(lds_bits));
+    // (the kernarg pointer is read HERE: asked for in the callee, this compiler's caller does not pass it on and the callee reads a stale register)
+#if __HIP_DEVICE_COMPILE__
+    const __attribute__((address_space(4))) PipeKernArgs* kp = (const __attribute__((address_space(4))) PipeKernArgs*) __builtin_amdgcn_kernarg_segment_ptr();
+    pipe_begin<METHOD, FAST, HOG>(&x, (const PipeKernArgs*) kp, reinterpret_cast<double*>((uintptr_t) lds_bits), HOG ? (long long) blockIdx.x * 64 : -1,       // one wave per workgroup, HOG or not
+                                  HOG ? (unsigned long long) gridDim.x * 64 : 0ull);
+    // The step loop's constants are loaded AFTER that call (the empty asm hides the pointer's origin): loaded at kernel entry, as arguments are,
+    // 18 of them sat in a spill register across the call and came back through ~50 v_readlane per step.
+    asm volatile("" : "+s"(kp));
     int has_prio = 0;
-    if constexpr (HOG) {
-        constexpr int kWaves = kHogBlock / 64;
-        const long long g = (long long) blockIdx.x * kWaves + (threadIdx.x >> 6);
-        trace_body<double, METHOD, false, FAST, HOG, REFILL_MIN>(io, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio, g * 64, (unsigned long long) gridDim.x * kWaves * 64);
-    } else {
-        trace_body<double, METHOD, false, FAST, HOG, REFILL_MIN>(io, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio);
-    }
-    if (args.use_lds) {
-        __syncthreads();
-        for (int w = threadIdx.x; w < words; w += block_of(HOG))
-            if (pipe_lds[w] != 0) atomicAdd(&args.hist[w], pipe_lds[w]);
-    }
+    trace_body_pipe<METHOD, FAST, HOG, REFILL_MIN>(&x, *(const TraceConsts<double>*) &kp->c, kp->counters, has_prio);
+#else
+    (void) ka;           // (host pass of the single-source compile: never executed)
+#endif
+    pipe_end<METHOD, FAST, HOG>(&x);
 }
 
 // ONE grid over MANY traces (kr_trace_batch_async_f64 when all traces of the batch use the same kernel instances).  Every wave serves
@@ -804,9 +1083,10 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     if (la.fixed_grid > 0) grid = la.fixed_grid;
     if constexpr (std::is_same<T, double>::value && !USE_DEST) {
         if (la.pipe) {
-            const size_t lds = la.pipe->use_lds ? (size_t) (5 * la.pipe->bins.nr + 1) * sizeof(double) : 0;
-            hipLaunchKernelGGL((trace_pipe_kernel<METHOD, FAST, HOG, kRefill>), dim3(grid), dim3(block_of(HOG)), lds, stream, *la.pipe, (long long) n, c, counters, la.list,
-                               la.n_ptr, la.n_mode, la.mask, la.mask_want);
+            static_assert(kHogBlock == 64, "the pipeline instances run one wave per workgroup (their LDS rings belong to a wave)");
+            const size_t lds = PipeRings::bytes(la.pipe->use_lds ? 5 * la.pipe->bins.nr + 1 : 0);
+            const PipeKernArgs ka{*la.pipe, (long long) n, c, counters, la.list, la.n_ptr, la.mask, la.n_mode, la.mask_want};
+            hipLaunchKernelGGL((trace_pipe_kernel<METHOD, FAST, HOG, kRefill>), dim3(grid), dim3(64), lds, stream, ka);
             KR_HIP(hipGetLastError());
             return KR_OK;
         }
@@ -1343,7 +1623,7 @@ int trace_shutdown()
 }
 
 // The emissivity pipeline (kr_emissivity_pipeline_dev_f64): source -> redshift_start -> run_raytrace -> redshift -> radial histogram as ONE trace
-// (classification + side launch + main launch like any other; EmisPipeIO), the rays living in registers from birth to bin.
+// (classification + side launch + main launch like any other; trace_body_pipe), the rays living in registers and LDS from birth to bin.
 int trace_pipeline_emis(const kr_params* p, const EmisPipeArgs* args, int64_t n, hipStream_t stream, kr_stats* stats)
 {
     if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->rays_total = n; }

@@ -19,18 +19,28 @@
 //   * a name longer than 8 characters, or with characters outside [A-Z0-9_-], becomes `HIERARCH NAME = value`.
 //   * COMMENT cards carry 72 characters each; the primary HDU starts with cfitsio's two standard COMMENT lines.
 //   * bytes outside printable ASCII (e.g. a UTF-8 dash in a comment) are written as blanks.
+//
+// Throughput: a 4096 x 4096 run writes six 134-MB images, and serially (transpose + byte swap into a zero-filled vector, then one ofstream
+// write) that was 1.3 s of the program's 1.85 s on the GPU box.  An image is now transposed / byte-swapped by a team of threads into one of
+// two reusable buffers and handed to a background writer that pwrite()s it in parallel slices while the application fills the next one
+// (KRTRACE_HOST_THREADS caps the team, default min(hardware threads, 16)).  Same bytes in the file.
 #ifndef FITS_OUTPUT_H_
 #define FITS_OUTPUT_H_
 
 #include <cctype>
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <unistd.h>
 using namespace std;
 
 #define COL_STRING "8A"
@@ -163,8 +173,12 @@ public:
     {
         if (!open_) return;
         flush_hdu();
-        file_.close();
+        for (int b = 0; b < 2; ++b) wait_for(b);
+        for (int b = 0; b < 2; ++b) { free(buf_[b]); buf_[b] = nullptr; cap_[b] = 0; }
+        if (::close(fd_) != 0) io_error_ = errno;
+        fd_ = -1;
         open_ = false;
+        if (io_error_) cerr << "FITSOutput ERROR : writing the file failed: " << strerror(io_error_) << endl;
     }
 
     // an empty primary array, so that keywords can be attached to the file as a whole
@@ -178,9 +192,11 @@ public:
     // ------ images ------
     void write_image_array(double* frame, int Nx, int Ny)
     {
-        begin_image(Nx, Ny);
+        uint64_t* out = begin_image(Nx, Ny);
         const size_t n = static_cast<size_t>(Nx) * Ny;
-        for (size_t i = 0; i < n; ++i) data_[i] = big_endian(frame[i]);
+        team(n, 1 << 16, [=](size_t a, size_t b) {
+            for (size_t i = a; i < b; ++i) out[i] = big_endian(frame[i]);
+        });
     }
 
     // data[x][y] -> image with X along FITS axis 1 (left to right) and Y along axis 2 (bottom to top); `transpose` swaps the
@@ -188,26 +204,34 @@ public:
     void write_image(T** data, int Nx, int Ny, bool transpose = false, bool flip_x = false, bool flip_y = false)
     {
         if (transpose) {
-            begin_image(Ny, Nx);
-            for (int j = 0; j < Nx; ++j) {
-                const T* row = data[flip_x ? Nx - 1 - j : j];
-                uint64_t* out = &data_[static_cast<size_t>(j) * Ny];
-                for (int k = 0; k < Ny; ++k) out[k] = big_endian(static_cast<double>(row[flip_y ? Ny - 1 - k : k]));
-            }
+            uint64_t* img = begin_image(Ny, Nx);
+            team(static_cast<size_t>(Nx), 8, [=](size_t a, size_t b) {
+                for (size_t j = a; j < b; ++j) {
+                    const T* row = data[flip_x ? Nx - 1 - static_cast<int>(j) : static_cast<int>(j)];
+                    uint64_t* out = img + j * Ny;
+                    for (int k = 0; k < Ny; ++k) out[k] = big_endian(static_cast<double>(row[flip_y ? Ny - 1 - k : k]));
+                }
+            });
             return;
         }
-        // out[k * Nx + j] = data[x(j)][y(k)] is a transposition: walk it in 32 x 32 tiles so that both sides stay in cache
-        begin_image(Nx, Ny);
+        // out[k * Nx + j] = data[x(j)][y(k)] is a transposition: walk it in 32 x 32 tiles so that both sides stay in cache; a thread owns
+        // whole tile ROWS of the output (k0 bands), so no two threads share a cache line of it
+        uint64_t* img = begin_image(Nx, Ny);
         constexpr int kTile = 32;
-        for (int j0 = 0; j0 < Nx; j0 += kTile)
-            for (int k0 = 0; k0 < Ny; k0 += kTile) {
-                const int j1 = j0 + kTile < Nx ? j0 + kTile : Nx, k1 = k0 + kTile < Ny ? k0 + kTile : Ny;
-                for (int j = j0; j < j1; ++j) {
-                    const T* row = data[flip_x ? Nx - 1 - j : j];
-                    for (int k = k0; k < k1; ++k)
-                        data_[static_cast<size_t>(k) * Nx + j] = big_endian(static_cast<double>(row[flip_y ? Ny - 1 - k : k]));
+        const size_t bands = (static_cast<size_t>(Ny) + kTile - 1) / kTile;
+        team(bands, 1, [=](size_t a, size_t b) {
+            for (size_t band = a; band < b; ++band) {
+                const int k0 = static_cast<int>(band) * kTile, k1 = k0 + kTile < Ny ? k0 + kTile : Ny;
+                for (int j0 = 0; j0 < Nx; j0 += kTile) {
+                    const int j1 = j0 + kTile < Nx ? j0 + kTile : Nx;
+                    for (int j = j0; j < j1; ++j) {
+                        const T* row = data[flip_x ? Nx - 1 - j : j];
+                        for (int k = k0; k < k1; ++k)
+                            img[static_cast<size_t>(k) * Nx + j] = big_endian(static_cast<double>(row[flip_y ? Ny - 1 - k : k]));
+                    }
                 }
             }
+        });
     }
 
     // one image extension per frame of data[frame][y][x], both axes mirrored (reference :190-207)
@@ -253,8 +277,8 @@ private:
         if (clobber) cout << " (will overwrite if file exists)" << endl;
         if (clobber) remove(filename);
         else if (ifstream(filename).good()) throw FITSOutputException("Could not open file", 105);
-        file_.open(filename, ios::out | ios::binary | ios::trunc);
-        if (!file_) throw FITSOutputException("Could not open file", 104);
+        fd_ = ::open(filename, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd_ < 0) throw FITSOutputException("Could not open file", 104);
         open_ = true;
     }
     void need_open() const
@@ -279,14 +303,71 @@ private:
         return __builtin_bswap64(bits);
     }
 
-    // a BITPIX = -64 image HDU of Nx x Ny pixels whose data_ the caller fills
-    void begin_image(int Nx, int Ny)
+    // a BITPIX = -64 image HDU of Nx x Ny pixels; the caller fills EVERY word of the returned buffer (it is not zeroed)
+    uint64_t* begin_image(int Nx, int Ny)
     {
         need_open();
         cout << "Adding " << Nx << 'x' << Ny << " image extension to FITS file" << endl;
         const long axes[2] = {Nx, Ny};
         new_hdu(-64, axes, 2);
-        data_.assign(static_cast<size_t>(Nx) * Ny, 0);
+        cur_ ^= 1;
+        wait_for(cur_);                              // the writer that last used this buffer
+        words_ = static_cast<size_t>(Nx) * Ny;
+        const size_t padded = (words_ * 8 + krhost::fits::kBlock - 1) / krhost::fits::kBlock * krhost::fits::kBlock;
+        if (cap_[cur_] < padded) {
+            free(buf_[cur_]);
+            buf_[cur_] = static_cast<uint64_t*>(malloc(padded));
+            if (!buf_[cur_]) throw FITSOutputException("out of memory for an image buffer");
+            cap_[cur_] = padded;
+        }
+        memset(reinterpret_cast<char*>(buf_[cur_]) + words_ * 8, 0, padded - words_ * 8);      // the block padding goes out with the data
+        have_data_ = true;
+        return buf_[cur_];
+    }
+
+    static int team_size()
+    {
+        unsigned hw = thread::hardware_concurrency();
+        int t = hw == 0 ? 4 : static_cast<int>(hw < 16 ? hw : 16);
+        if (const char* e = getenv("KRTRACE_HOST_THREADS")) {
+            const int v = atoi(e);
+            if (v >= 1 && v < t) t = v;
+        }
+        return t;
+    }
+
+    // fn(a, b) over [0, n) in contiguous pieces, one per thread; the calling thread takes the first piece
+    template <class F>
+    static void team(size_t n, size_t min_per_thread, F fn)
+    {
+        size_t t = static_cast<size_t>(team_size());
+        if (min_per_thread > 0 && n / min_per_thread < t) t = n / min_per_thread;
+        if (t <= 1) { fn(static_cast<size_t>(0), n); return; }
+        vector<thread> others;
+        others.reserve(t - 1);
+        for (size_t i = 1; i < t; ++i) others.emplace_back(fn, n * i / t, n * (i + 1) / t);
+        fn(static_cast<size_t>(0), n / t);
+        for (thread& th : others) th.join();
+    }
+
+    static int write_all(int fd, const char* p, size_t bytes, off_t at)
+    {
+        while (bytes > 0) {
+            const ssize_t w = ::pwrite(fd, p, bytes, at);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                return errno;
+            }
+            p += w; bytes -= static_cast<size_t>(w); at += w;
+        }
+        return 0;
+    }
+
+    void wait_for(int b)
+    {
+        if (writer_[b].joinable()) writer_[b].join();
+        if (writer_error_[b] && !io_error_) io_error_ = writer_error_[b];
+        writer_error_[b] = 0;
     }
 
     // mandatory cards of a new image HDU; the previous one goes to disk first
@@ -321,28 +402,62 @@ private:
         string end = "END";
         end.resize(kf::kCard, ' ');
         cards_.push_back(end);
+        string header;
+        header.reserve((cards_.size() + 36) * kf::kCard);
         for (string& c : cards_) {
             for (char& ch : c)                       // header bytes are printable ASCII; anything else becomes a blank
                 if (static_cast<unsigned char>(ch) < 32 || static_cast<unsigned char>(ch) > 126) ch = ' ';
-            file_.write(c.data(), kf::kCard);
+            header.append(c.data(), kf::kCard);
         }
-        const size_t used = cards_.size() * kf::kCard % kf::kBlock;
-        if (used) file_ << string(kf::kBlock - used, ' ');
-        if (!data_.empty()) {
-            const size_t bytes = data_.size() * 8;
-            file_.write(reinterpret_cast<const char*>(data_.data()), static_cast<streamsize>(bytes));
-            const size_t tail = bytes % kf::kBlock;
-            if (tail) file_ << string(kf::kBlock - tail, '\0');
+        const size_t used = header.size() % kf::kBlock;
+        if (used) header.append(kf::kBlock - used, ' ');
+        if (const int e = write_all(fd_, header.data(), header.size(), pos_)) {
+            if (!io_error_) io_error_ = e;
+        }
+        pos_ += static_cast<off_t>(header.size());
+        if (have_data_) {
+            // the image leaves in the background, in parallel slices, while the application builds the next one in the other buffer
+            const size_t bytes = (words_ * 8 + kf::kBlock - 1) / kf::kBlock * kf::kBlock;
+            const char* src = reinterpret_cast<const char*>(buf_[cur_]);
+            const int fd = fd_, b = cur_;
+            const off_t at = pos_;
+            int* err = &writer_error_[b];
+            writer_[b] = thread([=]() {
+                constexpr size_t kSlice = size_t(8) << 20;
+                const size_t slices = (bytes + kSlice - 1) / kSlice;
+                const int writers = slices < 4 ? static_cast<int>(slices) : 4;
+                vector<int> errs(static_cast<size_t>(writers), 0);
+                vector<thread> ths;
+                for (int w = 0; w < writers; ++w)
+                    ths.emplace_back([=, &errs]() {
+                        for (size_t s = static_cast<size_t>(w); s < slices && !errs[static_cast<size_t>(w)]; s += static_cast<size_t>(writers)) {
+                            const size_t off = s * kSlice, len = off + kSlice < bytes ? kSlice : bytes - off;
+                            errs[static_cast<size_t>(w)] = write_all(fd, src + off, len, at + static_cast<off_t>(off));
+                        }
+                    });
+                for (thread& t : ths) t.join();
+                for (int e : errs)
+                    if (e && !*err) *err = e;
+            });
+            pos_ += static_cast<off_t>(bytes);
+            have_data_ = false;
         }
         cards_.clear();
-        data_.clear();
     }
 
-    ofstream file_;
+    int fd_ = -1;
+    off_t pos_ = 0;              // where the next HDU starts
     bool open_ = false;
     int hdus_ = 0;
+    int io_error_ = 0;
     vector<string> cards_;
-    vector<uint64_t> data_;      // big-endian words of the current image
+    uint64_t* buf_[2] = {nullptr, nullptr};   // big-endian words of the current image / of the one being written
+    size_t cap_[2] = {0, 0};
+    size_t words_ = 0;
+    int cur_ = 0;
+    bool have_data_ = false;
+    thread writer_[2];
+    int writer_error_[2] = {0, 0};
 };
 
 #endif /* FITS_OUTPUT_H_ */
