@@ -714,6 +714,7 @@ def main():
                          "flop_per_step": FLOP_PER_STEP[args.integrator], "work_units_per_launch": int(units), "avg_kernel_ms": avg_kernel_ms,
                          "kernel_steps_per_sec": steps_total / (avg_kernel_ms * 1e-3),
                          "split_launch_ms": {"strict_side": stats_last.get("strict_side_ms", 0.0), "main": stats_last.get("main_ms", 0.0)},
+                         "longest_ray": critical_ray(stats_last, units, FLOP_PER_STEP[args.integrator]),
                          "hbm": {"algorithmic_bytes": 288 * int(traced), "achieved_gbs": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9,
                                  "peak_gbs": HBM_PEAK_GBS, "frac": 288 * traced / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "traffic": None, "traffic_from_profile": traffic_from_profile,
@@ -735,6 +736,19 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def critical_ray(st, units, flop_per_unit):
+    """What the launch's longest ray says about the roofline fraction (kr_stats.longest_ray_steps*): a ray is ONE sequential chain of steps
+    on a wave, so the launch that carries it lasts at least (its steps) x (that wave's time per step), however many CUs idle beside it.
+    For a split trace the strict side launch is that chain: `strict_side_us_per_step` is its duration over its longest ray's steps, and
+    `frac_cap` the roofline fraction the pass would have if it lasted exactly as long as that launch."""
+    out = {"steps": int(st.get("longest_ray_steps", 0))}
+    side_steps, side_ms = int(st.get("longest_ray_steps_strict_side", 0)), st.get("strict_side_ms", 0.0)
+    if side_steps > 0 and side_ms > 0:
+        out.update({"strict_side_steps": side_steps, "strict_side_ms": side_ms, "strict_side_us_per_step": 1e3 * side_ms / side_steps,
+                    "frac_cap": flop_per_unit * units / (side_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS})
+    return out
 
 
 def cpu_baseline_imageplane(args, capi, api, wl):

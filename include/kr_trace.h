@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 12
+#define KR_ABI_VERSION 13
 
 /* error codes */
 #define KR_OK          0
@@ -153,6 +153,10 @@ typedef struct kr_stats {
                                        limit (r, theta, every integer output exact; t, phi, momenta to ~1e-11) */
     double  strict_side_ms;         /* split traces: duration of the strict side launch (caller's stream) ... */
     double  main_ms;                /* ... and of the main launch beside it (internal stream); kernel_ms spans both.  0 otherwise */
+    int64_t longest_ray_steps;      /* most steps one ray took in this call: a ray is one sequential chain on a wave, so the launch that
+                                       carries it lasts at least this many wave steps whatever else the GPU does (DESIGN.md "Known limit") */
+    int64_t longest_ray_steps_strict_side; /* the same over the rays of the strict side launch of a split trace (0 otherwise):
+                                       strict_side_ms / this = that launch's time per step on a wave of its own */
 } kr_stats;
 
 /* PointSource<T> ctor arguments (pointsource.h:24, pointsource.cpp:11-64) */

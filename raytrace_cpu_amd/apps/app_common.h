@@ -7,6 +7,8 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/kr_trace.h"
 
@@ -91,6 +93,25 @@ public:
 private:
     std::chrono::steady_clock::time_point t0_;
 };
+
+// fn(begin, end) over [0, n) in contiguous pieces on min(hardware threads, 16, KRTRACE_HOST_THREADS) threads (the calling thread takes the first)
+template <class F>
+inline void parallel_for(int64_t n, F fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t t = hw == 0 ? 4 : (hw < 16 ? hw : 16);
+    if (const char* e = getenv("KRTRACE_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v < t) t = v;
+    }
+    if (n < (int64_t) 1 << 16) t = 1;
+    if (t <= 1) { fn((int64_t) 0, n); return; }
+    std::vector<std::thread> others;
+    others.reserve((size_t) t - 1);
+    for (int64_t i = 1; i < t; ++i) others.emplace_back(fn, n * i / t, n * (i + 1) / t);
+    fn((int64_t) 0, n / t);
+    for (std::thread& th : others) th.join();
+}
 
 }   // namespace krapp
 

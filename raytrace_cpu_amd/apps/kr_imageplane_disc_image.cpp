@@ -111,31 +111,35 @@ try {
     const double ms_post = clock.lap_ms();
 
     // ---- per-pixel means (imageplane_disc_image.cpp:165-174): flux only where rays arrived, the rest 0/0 -> NaN ---------
-    Array2D<int> disc_Nrays(ax.img_nx, ax.img_ny);
-    Array2D<double> disc_flux(ax.img_nx, ax.img_ny), disc_r(ax.img_nx, ax.img_ny), disc_phi(ax.img_nx, ax.img_ny), disc_enshift(ax.img_nx, ax.img_ny),
-        disc_time(ax.img_nx, ax.img_ny), disc_emis(ax.img_nx, ax.img_ny);
-    Array2D<double>* sums[6] = {&disc_flux, &disc_r, &disc_phi, &disc_enshift, &disc_time, &disc_emis};
-    for (int64_t i = 0; i < npix; ++i) {
-        disc_Nrays.ptr[0][i] = static_cast<int>(h[i]);
-        for (int k = 0; k < 6; ++k) sums[k]->ptr[0][i] = h[(k + 1) * npix + i];
-    }
+    // In place in the page-locked read-back buffer, on a team of threads: seven 134-MB Array2D copies, their zero-fill and six serial
+    // division passes were 0.3 s of this program at 4096 x 4096.
     const long disc_count = static_cast<long>(h[7 * npix]);
     cout << disc_count << " rays hit the disc" << endl;
-    for (int64_t i = 0; i < npix; ++i)
-        if (disc_Nrays.ptr[0][i] > 0) disc_flux.ptr[0][i] /= disc_Nrays.ptr[0][i];
-    disc_r /= disc_Nrays;
-    disc_phi /= disc_Nrays;
-    disc_enshift /= disc_Nrays;
-    disc_time /= disc_Nrays;
-    disc_emis /= disc_Nrays;
+    double* hp = h.data();
+    krapp::parallel_for(npix, [=](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) {
+            const int hits = static_cast<int>(hp[i]);
+            if (hits > 0) hp[npix + i] /= hits;
+            for (int k = 2; k <= 6; ++k) hp[k * npix + i] /= hits;
+        }
+    });
+    vector<vector<double*>> rows(6, vector<double*>(static_cast<size_t>(ax.img_nx)));
+    double** sums[6];
+    for (int k = 0; k < 6; ++k) {
+        for (int ix = 0; ix < ax.img_nx; ++ix) rows[k][ix] = hp + (k + 1) * npix + static_cast<int64_t>(ix) * ax.img_ny;
+        sums[k] = rows[k].data();
+    }
+    const double ms_means = clock.lap_ms();
 
     // ---- FITS (imageplane_disc_image.cpp:176-304) ----------------------------------------------------------------------
     krapp::DiscImageInfo info = {dist, incl, spin, r_isco, r_disc, q1, rb1, q2, rb2, q3, Nx * Ny, disc_count, ax};
     krapp::write_disc_image_fits(out_name, info, sums);
+    const double ms_fits = clock.lap_ms();
 
     if (timing)
         cout << "timing: rays " << st.rays_traced << " steps " << st.steps_total << " | init+redshift_start " << ms_init << " ms | trace " << ms_trace
-             << " ms (kernel " << st.kernel_ms << ") | redshift+range_phi+planes+readback " << ms_post << " ms" << endl;
+             << " ms (kernel " << st.kernel_ms << ") | redshift+range_phi+planes+readback " << ms_post << " ms | per-pixel means " << ms_means
+             << " ms | FITS file " << ms_fits << " ms" << endl;
     cout << "Done" << endl;
     return 0;
 } catch (const exception& e) {

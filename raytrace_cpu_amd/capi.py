@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -39,7 +39,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("rays_total", "rays_traced", "steps_total", "rk45_attempts", "rk45_rejects")] + \
                [(n, C.c_double) for n in ("kernel_ms", "h2d_ms", "d2h_ms")] + [("rays_strict_side", C.c_int64), ("rk45_stationary_steps", C.c_int64), ("rk45_extrapolated_steps", C.c_int64)] + \
-               [("strict_side_ms", C.c_double), ("main_ms", C.c_double)]
+               [("strict_side_ms", C.c_double), ("main_ms", C.c_double), ("longest_ray_steps", C.c_int64), ("longest_ray_steps_strict_side", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

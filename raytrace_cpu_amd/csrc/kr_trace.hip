@@ -80,7 +80,8 @@ constexpr int block_of(bool hog) { return hog ? kHogBlock : kTraceBlock; }
 #ifndef KR_OCC_STATS
 #define KR_OCC_STATS 0               // 1: lane-occupancy bookkeeping of the step loop (diagnostic builds: scripts/gpu_occ_stats.sh), printed by trace_wait
 #endif
-constexpr int kCounters = KR_OCC_STATS ? 12 : 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps, [6] rk45 extrapolated steps
+constexpr int kCounters = KR_OCC_STATS ? 13 : 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps, [6] rk45 extrapolated steps,
+                                                         // [7] steps of the launch's longest ray (atomicMax); KR_OCC_STATS builds: [8..12] occupancy sums
 constexpr int kCounterBlocks = 4;    // main launch, strict side launch, strict overflow launch, split bookkeeping ([1] = number of ill-conditioned rays)
 constexpr int kListCap = 32768;      // index-list entries of the strict side launch (= 128 workgroups x 256 lanes, half of the chip)
 
@@ -191,6 +192,16 @@ __device__ __attribute__((noinline)) void pipe_sink(const EmisPipeArgs& a, doubl
     emissivity_accumulate(hist, a.bins, log_dr, out_steps, r, theta, g, t);
 }
 
+KR_DEV unsigned long long wave_max(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
 template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 {
 #pragma unroll
@@ -252,6 +263,7 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
     bool pend = false;          // this lane's ray has ended and is still in its registers: written out at the wave's next visit to the queue (or on exit)
     bool exhausted = false;     // wave-uniform: the queue head has passed n
     unsigned long long my_steps = 0, my_traced = 0;
+    int32_t my_longest = 0;     // most steps any of this lane's rays took in this call
     uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
 #if KR_LONG_RAY_PRIO
     unsigned prio_tick = 0;
@@ -274,6 +286,7 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
                 // (not under a divergent branch of its own in the step loop: that branch ran in one wave iteration out of nine for a single
                 // lane's ~40 instructions)
                 my_steps += (unsigned long long) s.steps;
+                my_longest = s.steps > my_longest ? s.steps : my_longest;
                 io.store(idx, s, finish_status<T, USE_DEST>(s, c));
                 pend = false;
             }
@@ -378,16 +391,18 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
     const unsigned long long w_rej = wave_sum<T>((unsigned long long) my_rejects);
     const unsigned long long w_sta = wave_sum<T>((unsigned long long) my_stationary);
     const unsigned long long w_creep = wave_sum<T>((unsigned long long) my_creep);
+    const unsigned long long w_longest = wave_max((unsigned long long) my_longest);
 #if KR_OCC_STATS
     {
         const unsigned long long w_tail_steps = wave_sum<T>(occ_tail_steps);
         if (lane == 0) {
-            atomicAdd(&counters[7], occ_iters); atomicAdd(&counters[8], occ_tail_iters); atomicAdd(&counters[9], w_tail_steps);
-            atomicAdd(&counters[10], occ_refills); atomicAdd(&counters[11], occ_refill_lanes);
+            atomicAdd(&counters[8], occ_iters); atomicAdd(&counters[9], occ_tail_iters); atomicAdd(&counters[10], w_tail_steps);
+            atomicAdd(&counters[11], occ_refills); atomicAdd(&counters[12], occ_refill_lanes);
         }
     }
 #endif
     if (lane == 0) {
+        if (w_longest) atomicMax(&counters[7], w_longest);
         if (w_sta) atomicAdd(&counters[5], w_sta);
         if (w_creep) atomicAdd(&counters[6], w_creep);
         if (w_traced) atomicAdd(&counters[1], w_traced);
@@ -419,7 +434,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
 // state (PipeCtx: the two ring fills, the queue, copies of the arguments).  The step loop around it then carries strictly less than the record
 // kernel's does -- the visit's scalars had pushed the loop's hoisted constants out of the scalar file into a spill register and from there the
 // polynomial constants into scratch: ~11 scratch accesses and ~80 extra vector instructions PER STEP (main launch 102 ms against 64).
-struct PipeParked { Lane<double> s; unsigned long long my_steps, my_traced; int meta0; bool have, pend; };
+struct PipeParked { Lane<double> s; unsigned long long my_steps, my_traced; int meta0, my_longest; bool have, pend; };
 struct PipeCtx {
     EmisPipeArgs a;
     TraceConsts<double> c;
@@ -456,6 +471,7 @@ __device__ __attribute__((noinline)) bool pipe_visit(PipeParked* pk, PipeCtx* x,
         if (pk->pend) {
             const int e = out_count + __popcll(pm & lanes_below);
             pk->my_steps += (unsigned long long) s.steps;
+            pk->my_longest = s.steps > pk->my_longest ? s.steps : pk->my_longest;
             ring_i(x, PipeRings::kOutSteps, e) = finish_status<T, false>(s, x->c);
             ring_d(x, PipeRings::kOutR, e) = s.r; ring_d(x, PipeRings::kOutTheta, e) = s.theta; ring_d(x, PipeRings::kOutT, e) = s.t;
             ring_d(x, PipeRings::kOutK, e) = s.k; ring_d(x, PipeRings::kOutH, e) = s.h; ring_d(x, PipeRings::kOutQ, e) = s.Q;
@@ -552,8 +568,10 @@ KR_DEV void trace_body_pipe(PipeCtx* x, const TraceConsts<double>& c, unsigned l
     bool have = false, pend = false;
     bool dry = false;           // wave-uniform: queue exhausted and in-ring empty
     unsigned long long my_steps = 0, my_traced = 0;
+    int32_t my_longest = 0;
     uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
     PipeParked pk;
+    pk.my_longest = 0;          // (only the visit touches it)
 #if KR_OCC_STATS
     unsigned long long occ_iters = 0, occ_tail_iters = 0, occ_tail_steps = 0, occ_refills = 0, occ_refill_lanes = 0;
 #endif
@@ -574,7 +592,7 @@ KR_DEV void trace_body_pipe(PipeCtx* x, const TraceConsts<double>& c, unsigned l
             pk.s = s; pk.meta0 = meta0; pk.have = have; pk.pend = pend; pk.my_steps = my_steps; pk.my_traced = my_traced;
             dry = __any(pipe_visit<METHOD, FAST, HOG>(&pk, x, leaving));
             s = pk.s; meta0 = pk.meta0; have = pk.have; pend = pk.pend; my_steps = pk.my_steps; my_traced = pk.my_traced;
-            if (leaving) break;
+            if (leaving) { my_longest = pk.my_longest; break; }
             continue;
         }
 
@@ -616,16 +634,18 @@ KR_DEV void trace_body_pipe(PipeCtx* x, const TraceConsts<double>& c, unsigned l
     const unsigned long long w_rej = wave_sum<T>((unsigned long long) my_rejects);
     const unsigned long long w_sta = wave_sum<T>((unsigned long long) my_stationary);
     const unsigned long long w_creep = wave_sum<T>((unsigned long long) my_creep);
+    const unsigned long long w_longest = wave_max((unsigned long long) my_longest);
 #if KR_OCC_STATS
     {
         const unsigned long long w_tail_steps = wave_sum<T>(occ_tail_steps);
         if (lane == 0) {
-            atomicAdd(&counters[7], occ_iters); atomicAdd(&counters[8], occ_tail_iters); atomicAdd(&counters[9], w_tail_steps);
-            atomicAdd(&counters[10], occ_refills); atomicAdd(&counters[11], occ_refill_lanes);
+            atomicAdd(&counters[8], occ_iters); atomicAdd(&counters[9], occ_tail_iters); atomicAdd(&counters[10], w_tail_steps);
+            atomicAdd(&counters[11], occ_refills); atomicAdd(&counters[12], occ_refill_lanes);
         }
     }
 #endif
     if (lane == 0) {
+        if (w_longest) atomicMax(&counters[7], w_longest);
         if (w_sta) atomicAdd(&counters[5], w_sta);
         if (w_creep) atomicAdd(&counters[6], w_creep);
         if (w_traced) atomicAdd(&counters[1], w_traced);
@@ -1534,12 +1554,13 @@ int trace_wait(void* ticket, kr_stats* stats)
         const unsigned long long* h2 = ws->h_counters;
         unsigned long long h[kCounters];
         for (int i = 0; i < kCounters; i++) h[i] = h2[i] + h2[kCounters + i] + h2[2 * kCounters + i];
+        h[7] = std::max(h2[7], std::max(h2[kCounters + 7], h2[2 * kCounters + 7]));      // a maximum, not a sum
 #if KR_OCC_STATS
         for (int b = 0; b < 3; b++) {
             const unsigned long long* q = h2 + b * kCounters;
-            if (q[7]) std::fprintf(stderr, "kr_occ: launch %d (0 main, 1 strict side, 2 overflow): steps %llu wave_iters %llu step-loop lane occupancy %.4f | after queue exhaustion: "
-                                   "wave_iters %llu (%.2f %%) lane occupancy %.4f | refills %llu lanes/refill %.2f\n", b, q[2], q[7], (double) q[2] / (64.0 * q[7]), q[8],
-                                   100.0 * q[8] / q[7], q[8] ? (double) q[9] / (64.0 * q[8]) : 0.0, q[10], q[10] ? (double) q[11] / q[10] : 0.0);
+            if (q[8]) std::fprintf(stderr, "kr_occ: launch %d (0 main, 1 strict side, 2 overflow): steps %llu wave_iters %llu step-loop lane occupancy %.4f | after queue exhaustion: "
+                                   "wave_iters %llu (%.2f %%) lane occupancy %.4f | refills %llu lanes/refill %.2f | longest ray %llu steps\n", b, q[2], q[8], (double) q[2] / (64.0 * q[8]), q[9],
+                                   100.0 * q[9] / q[8], q[9] ? (double) q[10] / (64.0 * q[9]) : 0.0, q[11], q[11] ? (double) q[12] / q[11] : 0.0, q[7]);
         }
 #endif
         stats->rays_total = ws->n;
@@ -1550,6 +1571,8 @@ int trace_wait(void* ticket, kr_stats* stats)
         stats->rk45_rejects = (int64_t) h[4];
         stats->rk45_stationary_steps = (int64_t) h[5];
         stats->rk45_extrapolated_steps = (int64_t) h[6];
+        stats->longest_ray_steps = (int64_t) h[7];
+        stats->longest_ray_steps_strict_side = ws->split ? (int64_t) h2[kCounters + 7] : 0;
         float ms = 0;
         KR_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
         stats->kernel_ms = ms;

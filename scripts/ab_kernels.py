@@ -41,7 +41,7 @@ n = first.kr_pointsource_count(C.byref(spec), None, None)
 d_rays = C.c_void_p()
 capi.check(first, first.kr_malloc(C.byref(d_rays), n * 144), "malloc")
 p = capi.default_params(bench.SPIN); p.integrator, p.r_max = method, bench.R_MAX
-times = {t: [] for t, _ in specs}; steps = {}
+times = {t: [] for t, _ in specs}; steps = {}; sides = {}
 for rnd in range(a.rounds + 1):
     for tag, _ in specs:
         lib = libs[tag]
@@ -52,9 +52,11 @@ for rnd in range(a.rounds + 1):
         capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, C.byref(st)), "trace")
         if rnd > 0:
             times[tag].append(st.kernel_ms)
+            sides.setdefault(tag, []).append((st.strict_side_ms, st.main_ms))
         steps[tag] = st.steps_total
 base = np.median(times[specs[0][0]])
 for tag, fl in specs:
     t = np.array(times[tag])
     print(json.dumps({"variant": tag, "flags": fl, "rays": int(n), "steps": int(steps[tag]), "kr_flags": kr_flags[tag], "kernel_ms_median": float(np.median(t)), "kernel_ms_min": float(t.min()),
-                      "steps_per_sec": steps[tag] / (np.median(t) * 1e-3), "speedup_vs_first": float(base / np.median(t))}))
+                      "steps_per_sec": steps[tag] / (np.median(t) * 1e-3), "speedup_vs_first": float(base / np.median(t)),
+                      "strict_side_ms_median": float(np.median([x[0] for x in sides[tag]])), "main_ms_median": float(np.median([x[1] for x in sides[tag]]))}))

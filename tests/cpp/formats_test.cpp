@@ -73,10 +73,11 @@ static int redo_fits(const char* par_name, const char* planes_name, long disc_co
     ax.img_ny = par.get_parameter<int>("img_Ny", ax.img_nx);
     Array2D<double> a0(ax.img_nx, ax.img_ny), a1(ax.img_nx, ax.img_ny), a2(ax.img_nx, ax.img_ny), a3(ax.img_nx, ax.img_ny), a4(ax.img_nx, ax.img_ny),
         a5(ax.img_nx, ax.img_ny);
-    Array2D<double>* planes[6] = {&a0, &a1, &a2, &a3, &a4, &a5};
+    Array2D<double>* arrays[6] = {&a0, &a1, &a2, &a3, &a4, &a5};
     ifstream in(planes_name, ios::binary);
-    for (auto* p : planes) p->read(&in);
+    for (auto* p : arrays) p->read(&in);
     if (!in) { cerr << "short planes file" << endl; return 2; }
+    double** planes[6] = {a0.ptr, a1.ptr, a2.ptr, a3.ptr, a4.ptr, a5.ptr};
     krapp::write_disc_image_fits(out_name, info, planes);
     return 0;
 }

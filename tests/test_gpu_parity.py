@@ -41,6 +41,10 @@ def test_trace_vs_golden(krlib, case_name, run, flags):
     params = case["runs"][run]
     out, st = hip_pipeline(case, params, g["init"], flags)
     want = g[f"final__{run}"]
+    # kr_stats.longest_ray_steps: the step count of the call's longest ray (every ray of a fixture starts at steps = 0)
+    traced = out["steps"] != -1
+    assert st["longest_ray_steps"] == (int(np.abs(out["steps"][traced]).max()) if traced.any() else 0)
+    assert 0 <= st["longest_ray_steps_strict_side"] <= st["longest_ray_steps"]
     rtol = parity.rtol_for(params)
     slack = parity.steps_slack_for(params, flags)
     mode = {0: "strict", capi.FLAG_FAST_MATH: "fastmath", capi.FLAG_HYBRID: "hybrid"}[flags]

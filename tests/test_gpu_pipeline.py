@@ -76,7 +76,7 @@ def test_kernel_pipeline_equals_the_record_pipeline(krlib, integrator, mode):
     got, st_g = kernel_pipeline(lib, spec, p, bins, 0, 1, n)
     assert want[5 * bins.nr] > 0
     same_histogram(got, want, bins.nr)
-    for k in ("rays_traced", "steps_total", "rays_strict_side", "rk45_attempts", "rk45_rejects"):
+    for k in ("rays_traced", "steps_total", "rays_strict_side", "rk45_attempts", "rk45_rejects", "longest_ray_steps", "longest_ray_steps_strict_side"):
         assert st_g[k] == st_w[k], (k, st_g[k], st_w[k])
 
 
