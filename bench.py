@@ -746,8 +746,9 @@ def critical_ray(st, units, flop_per_unit):
     out = {"steps": int(st.get("longest_ray_steps", 0))}
     side_steps, side_ms = int(st.get("longest_ray_steps_strict_side", 0)), st.get("strict_side_ms", 0.0)
     if side_steps > 0 and side_ms > 0:
-        out.update({"strict_side_steps": side_steps, "strict_side_ms": side_ms, "strict_side_us_per_step": 1e3 * side_ms / side_steps,
-                    "frac_cap": flop_per_unit * units / (side_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS})
+        out.update({"strict_side_steps": side_steps, "strict_side_ms": side_ms, "strict_side_us_per_step": 1e3 * side_ms / side_steps})
+        if side_ms >= 0.5 * st.get("kernel_ms", 0.0):           # (a cap only where that launch is a large part of the pass)
+            out["frac_cap"] = flop_per_unit * units / (side_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS
     return out
 
 

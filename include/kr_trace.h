@@ -253,7 +253,7 @@ int kr_trace_async_f32(const kr_params* p, void* d_rays, int64_t n, void* stream
 int kr_trace_batch_async_f64(int32_t count, const kr_params* const* p, void* const* d_rays, const int64_t* n, void* const* streams, void** tickets);
 int kr_trace_wait(void* ticket, kr_stats* stats);
 /* kr_trace_wait on `count` tickets (a batch's, in any order).  per_ticket (optional): count records; total (optional): the counters summed
- * (rays_total, rays_traced, steps_total, rk45_*, rays_strict_side) and the LARGEST kernel_ms / strict_side_ms / main_ms.  Every ticket is
+ * (rays_total, rays_traced, steps_total, rk45_*, rays_strict_side) and the LARGEST kernel_ms / strict_side_ms / main_ms / longest_ray_steps*.  Every ticket is
  * released, also when one of them fails (the first error code is returned). */
 int kr_trace_wait_many(int32_t count, void* const* tickets, kr_stats* per_ticket, kr_stats* total);
 int kr_trace_release(void* ticket);

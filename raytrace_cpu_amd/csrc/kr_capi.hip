@@ -345,6 +345,8 @@ int kr_trace_wait_many(int32_t count, void* const* tickets, kr_stats* per_ticket
             total->kernel_ms = std::max(total->kernel_ms, st.kernel_ms);
             total->strict_side_ms = std::max(total->strict_side_ms, st.strict_side_ms);
             total->main_ms = std::max(total->main_ms, st.main_ms);
+            total->longest_ray_steps = std::max(total->longest_ray_steps, st.longest_ray_steps);
+            total->longest_ray_steps_strict_side = std::max(total->longest_ray_steps_strict_side, st.longest_ray_steps_strict_side);
         }
     }
     return first_rc;
