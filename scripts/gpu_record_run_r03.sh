@@ -20,6 +20,7 @@ for f in sorted(glob.glob("gpurun_out/record_r03/bench_*.json")):
                 c = d["cpu_baseline"]; print("   cpu_baseline", {k: c[k] for k in ("value", "cores", "kind", "wall_s") if k in c}, c.get("sample", "")[:80], c.get("rays_check"), c.get("bins_check"))
 PY
 timeout -k 10 300 python bench.py --pipeline kernel --no-cpu-baseline > $O/bench_n1_emissivity_pipeline_kernel.json 2> $O/err_pk.txt || tail -3 $O/err_pk.txt
+[ -x scripts/microbench/lone_wave_ilp ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o scripts/microbench/lone_wave_ilp scripts/microbench/lone_wave_ilp.hip
 timeout -k 10 120 scripts/microbench/lone_wave_ilp > $O/lone_wave_ilp.txt 2>&1
 timeout -k 10 600 scripts/app_wall.sh > /dev/null 2>&1; cp gpurun_out/app_wall.txt $O/app_wall.txt; grep -E "^==|^wall" $O/app_wall.txt
 timeout -k 10 600 python scripts/rk45_tol_sweep.py strict > $O/rk45_tol_sweep_strict.json 2> $O/err_sweep.txt
