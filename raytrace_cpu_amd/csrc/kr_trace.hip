@@ -1086,7 +1086,7 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     // Resident workgroups per CU (= waves per SIMD).  The launch ends with its longest ray, which advances one step
     // per turn of its wave: with w waves per SIMD that turn comes round ~w times slower, while throughput keeps
     // improving up to ~3 waves.  Measured on MI355X, RK4 f64 strict, kernel ms at 1 / 2 / 3 workgroups per CU:
-    //   PointSource 1e7 rays (longest ray 34 527 steps)  211 / 165 / 183      PointSource 3e7 rays   - / 455 / 432
+    //   PointSource 1e7 rays (longest ray 39 280 steps)  211 / 165 / 183      PointSource 3e7 rays   - / 455 / 432
     //   ImagePlane 4097^2 rays (longest ~2 000 steps)     480 / 344 / 318      fast-math 1e7 rays   176 / 121 / 110
     // Default: 3 when the launch is long enough for throughput to dominate (n >= 2e7, or fast-math with n >= 5e6),
     // else 2.  kr_params.flags bits 8..11 (KR_FLAG_BLOCKS_PER_CU) or the KR_BLOCKS_PER_CU environment variable override.
