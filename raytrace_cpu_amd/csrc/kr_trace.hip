@@ -710,8 +710,10 @@ __device__ __attribute__((noinline)) void pipe_end(PipeCtx* x)
         if (lds[w] != 0) atomicAdd(&x->a.hist[w], lds[w]);
 }
 
+// (the pipeline instances carry their rings in LDS and their visit as a call: 3 waves per SIMD at most, also for Euler)
+#define KR_PIPE_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK45 ? 2 : 3, HOG ? KR_HOG_MAX_WAVES : 8)))
 template <int METHOD, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64))) KR_HOG_ATTR
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64))) KR_PIPE_ATTR
 trace_pipe_kernel(PipeKernArgs ka)
 {
     if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
