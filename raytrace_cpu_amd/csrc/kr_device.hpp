@@ -744,19 +744,24 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         // then r is NaN after this step whatever its length
         step = __builtin_fmax(step, T(KR_MIN_STEP));
         // the two landing clips apply on a ray's LAST step only: one fused test each, the clip itself behind a wave-uniform branch (the empty
-        // asm keeps the compiler from turning the branch back into unconditional arithmetic and selects)
+        // asm keeps the compiler from turning the branch back into unconditional arithmetic and selects).  The clipped step is the reference's
+        // correctly rounded quotient: it decides whether theta + thetadot step lands ON the limit or an ulp short of it (= one more step).
+        // With the heuristic's approximate reciprocal (2^-44) 23 of 1e6 Euler rays of a lamp post at a = 0 took that extra step
+        // (profiles/r03_hybrid_sweep_euler.jsonl, tests/tool_gpu_euler_diff.py).
         {
-            const bool clip_r = __builtin_fma(pr1, step, s.r) > c.rlim;
-            if (__builtin_amdgcn_ballot_w64(clip_r) != 0) {
+            // (the fused sum is within an ulp of the reference's rounded product + rounded sum: ">=" lets every ray through that the reference's
+            // own test, made inside, could clip)
+            const bool near_r = __builtin_fma(pr1, step, s.r) >= c.rlim;
+            if (__builtin_amdgcn_ballot_w64(near_r) != 0) {
                 asm volatile("" ::: "memory");
-                if (clip_r) step = kr_abs(c.rlim - s.r) * inv_pr;
+                if (near_r && s.r + pr1 * step > c.rlim) step = kr_abs(lean_div(c.rlim - s.r, pr1));
             }
         }
         if (!USE_DEST) {
-            const bool clip_th = __builtin_fma(ptheta1, step, s.theta) > c.theta_hi;
-            if (__builtin_amdgcn_ballot_w64(clip_th) != 0) {
+            const bool near_th = __builtin_fma(ptheta1, step, s.theta) >= c.theta_hi;
+            if (__builtin_amdgcn_ballot_w64(near_th) != 0) {
                 asm volatile("" ::: "memory");
-                if (clip_th) step = kr_abs(c.theta_hi - s.theta) * inv_pth;
+                if (near_th && s.theta + ptheta1 * step > c.theta_hi) step = kr_abs(lean_div(c.theta_hi - s.theta, ptheta1));
             }
         }
         if (pt1 <= 0) s.status |= KR_STATUS_ERGO;

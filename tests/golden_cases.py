@@ -7,6 +7,7 @@ stay small:
   ps_h10   BASELINE.json configs[0..1]: par_example/emissivity.par_example source + --source_h=10
   ps_kep   src/tests/raytrace_rk4_test.cpp:26-32 (Keplerian source, default angular limits); ps_kep5k: the same on 5000 rays
   ps_h5_a05, ps_h10_a0   lamp posts at a = 0.5 / a = 0 for the RayDestination overloads (raytracer.cpp:1036-1254, :1600-1894)
+  ps_h10_a0_landing      two rows of a 1e6-ray grid of the a = 0 lamp post: the clipped last step onto the disc (raytracer.cpp:870-871, :242-243)
   ip15/16  par_example/imageplane_disc_image.par_example geometry on a 16x16 / 17x17 ray grid
            (the 17x17 grid contains the (0,0) pixel whose constants are NaN)
 """
@@ -95,6 +96,16 @@ def cases():
                 "rk45_isco": _params(capi.RK45, capi.STOP_DISC_ISCO, (ri, 400.0, half_pi), spin=spin),
                 "rk45_flatdisc": _params(capi.RK45, capi.STOP_FLATDISC, (half_pi,), spin=spin),
             })
+    # Landing on the disc: two rows (cos alpha ~ -0.64) of the 1000 x 1000 grid of tests/tool_gpu_hybrid_sweep.py's "lamp h=10 a=0", theta-limit
+    # overload.  The clipped last step |(theta_lim - theta) / thetadot| decides whether theta lands ON the limit or an ulp short of it (one more
+    # step): with an approximate reciprocal in that quotient 12 of these 2 000 Euler rays took the extra step (profiles/r03_hybrid_sweep_euler.jsonl,
+    # first version) -- held to ZERO step-count differences in every arithmetic mode (test_trace_vs_golden).
+    d_landing = 1.99 / 999.0
+    c["ps_h10_a0_landing"] = dict(
+        source=ol.pointsource_spec([0.0, 10.0, 1e-3, 0.0], 0.0, 0.0, d_landing, d_landing * np.pi / 0.995, cosalpha0=-0.995 + 178 * d_landing,
+                                   cosalphamax=-0.995 + 180 * d_landing + 1e-9, beta0=-np.pi, betamax=np.pi),
+        start=(0.0, 0, 0), post=(-1.0, 0, 0),
+        runs={"euler": _params(capi.EULER, spin=0.0), "rk4": _params(capi.RK4, spin=0.0)})
     ip = dict(dist=10000.0, inc_deg=80.0, x0=-30.0, xmax=30.0, y0=-30.0, ymax=30.0, spin=SPIN)
     incl = 80.0 * np.pi / 180
     c["ip15"] = dict(
