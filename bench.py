@@ -584,7 +584,20 @@ def main():
         # under torch.distributed.run the collective path is used even with one rank, so that it is exercised on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a five-line version banner on STDOUT when its first communicator comes up; stdout carries rank 0's ONE JSON line and
+        # nothing else, so the communicator is created (a first all-reduce) with file descriptor 1 pointing at stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     if args.workload == "return_radiation" and args.integrator == "rk4" and "--integrator" not in " ".join(sys.argv):
         args.integrator = "euler"         # the reference driver uses the Euler integrator (disc_source_photonfrac_r.cpp:92)

@@ -19,15 +19,17 @@ def test_bench_line_and_kernel_overlap_under_rccl():
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                   # ONE json line
+    assert len(lines) == 1                                   # ONE json line ...
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1, r.stdout[:400]     # ... and nothing else on stdout (RCCL's version banner goes to stderr)
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["metric"] == "rays_per_sec" and d["unit"] == "rays/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64"
     assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
     roof = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "longest_ray"):
         assert key in roof, key
+    assert roof["longest_ray"]["steps"] == roof["longest_ray"]["strict_side_steps"] > 30000        # the polar-axis crawler of the beta = -pi column
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert d["config"]["rays_on_strict_side_launch"] == 3162
     # value is what the timed region did: rays * steps / wall
