@@ -65,8 +65,10 @@ def self_launch(argv, gpus):
     print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     for line in child.stdout:
-        sys.stdout.write(line)
-        sys.stdout.flush()
+        # (anything a library of the ranks still prints on stdout -- RCCL has a version banner -- goes to stderr: stdout is the JSON line's)
+        out = sys.stdout if line.startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
     return child.wait()
 
 
