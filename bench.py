@@ -512,15 +512,24 @@ class ReturnRadiationWorkload:
         # (the 100 source and 100 reducer kernels stay on this one stream: spread over 2 / 4 auxiliary streams the pass took 236 / 252 ms instead
         # of 233 -- streams that wait on the merged batch slow it down, profiles/r03_ab_experiments.txt)
         st_of = [stream] * len(self.specs)
-        for j, s in enumerate(self.specs):
-            capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(s), 0, 1, s.V, 0, 0, vp(self.buffers[j].data_ptr()), self.counts[j], vp(st_of[j])), "init+redshift_start (fused)")
-        tickets = self.api.trace_batch_async([self.p] * len(self.specs), [b.data_ptr() for b in self.buffers], self.counts, st_of)
-        for j, ((ir, r_s), s) in enumerate(zip(self.radii, self.specs)):
-            rays_k, n = self.buffers[j].data_ptr(), self.counts[j]
-            b = capi.ReturnBins()
-            b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, r_s, 1.5707
-            b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
-            capi.check(lib, lib.kr_post_return_dev_f64(-math.pi, math.pi, C.byref(b), vp(rays_k), n, vp(d_res + 32 * ir), vp(st_of[j])), "range_phi+reduce (fused)")
+        k = len(self.specs)
+        if getattr(self, "batch_args", None) is None:
+            # the host-side argument arrays of the two batched O(N) passes (all radii in ceil(k / 24) + ceil(k / 32) launches instead of 2 k)
+            specs = (capi.PointSourceSpec * k)(*self.specs)
+            V = (C.c_double * k)(*[s.V for s in self.specs])
+            ptrs = (C.c_void_p * k)(*[b.data_ptr() for b in self.buffers])
+            ns = (C.c_int64 * k)(*self.counts)
+            bins = (capi.ReturnBins * k)()
+            for j, (ir, r_s) in enumerate(self.radii):
+                b = bins[j]
+                b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, r_s, 1.5707
+                b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
+            self.batch_args = (specs, V, ptrs, ns, bins)
+        specs, V, ptrs, ns, bins = self.batch_args
+        capi.check(lib, lib.kr_pointsource_init_emit_batch_dev_f64(k, specs, V, 0, 0, ptrs, ns, vp(stream)), "init+redshift_start (fused, all radii)")
+        tickets = self.api.trace_batch_async([self.p] * k, [b.data_ptr() for b in self.buffers], self.counts, st_of)
+        outs = (C.c_void_p * k)(*[d_res + 32 * ir for ir, _ in self.radii])
+        capi.check(lib, lib.kr_post_return_batch_dev_f64(k, -math.pi, math.pi, bins, ptrs, ns, outs, vp(stream)), "range_phi+reduce (fused, all radii)")
         t1.record(cur)
         tot = self.api.trace_wait_many(tickets)          # one call for the hundred tickets: their counters summed
         t1.synchronize()

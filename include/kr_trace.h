@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 13
+#define KR_ABI_VERSION 14
 
 /* error codes */
 #define KR_OK          0
@@ -305,6 +305,12 @@ int kr_imageplane_init_strided_dev_f64(const kr_imageplane* s, int64_t first, in
  * (raytracer.cpp:603-622, :420-553, emissivity.cpp:96-126); rays[] ends up exactly as after the separate calls. */
 int kr_pointsource_init_emit_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d_rays, int64_t count,
                                      void* stream);
+/* `count` sources at once -- the multi-radius drivers (disc_source_photonfrac_r.cpp:74-92: one PointSource per radius): what `count` calls of
+ * kr_pointsource_init_emit_dev_f64(&s[i], 0, 1, V ? V[i] : s[i].V, reverse, projradius, d_rays[i], n[i], stream) write, bit for bit, in
+ * ceil(count / 24) kernel launches instead of `count` (a hundred launches of 1e6 rays each reach a third of the store bandwidth of one large one).
+ * s, V (may be NULL), d_rays and n are HOST arrays of `count` entries, read before the call returns. */
+int kr_pointsource_init_emit_batch_dev_f64(int32_t count, const kr_pointsource* s, const double* V, int reverse, int projradius, void* const* d_rays, const int64_t* n,
+                                           void* stream);
 /* The emissivity pipeline of src/emissivity/emissivity.cpp:60-126 -- PointSource ctor, redshift_start(V_start, ...), run_raytrace(theta_max, r_max),
  * redshift(V, ...), radial histogram -- as ONE trace whose rays never exist in memory: a lane builds source ray `first + slot * stride` in
  * registers when it takes slot `slot` (0 <= slot < count) off the work queue and adds the finished ray to the histogram (LDS per workgroup,
@@ -353,6 +359,10 @@ int kr_reduce_return_f64(const kr_return_bins* b, const kr_ray_f64* rays, int64_
 int kr_reduce_return_dev_f64(const kr_return_bins* b, const void* d_rays, int64_t n, void* d_out4, void* stream);
 /* range_phi(lo, hi) + kr_reduce_return_dev_f64 in one pass over the records (the returning-radiation driver's two passes after a trace) */
 int kr_post_return_dev_f64(double lo, double hi, const kr_return_bins* b, void* d_rays, int64_t n, void* d_out4, void* stream);
+/* kr_post_return_dev_f64 for `count` launches' rays at once: b, d_rays, n, d_out4 are HOST arrays of `count` entries (d_out4[i]: 4 doubles on the
+ * device, ADDED into); the same rays[] and, up to the order of the additions, the same sums as `count` single calls, in ceil(count / 32) launches. */
+int kr_post_return_batch_dev_f64(int32_t count, double lo, double hi, const kr_return_bins* b, void* const* d_rays, const int64_t* n, void* const* d_out4,
+                                 void* stream);
 
 /* ---- diagnostics ------------------------------------------------------------------------------- */
 /* out[i] = op(a[i], b[i]) evaluated ON THE DEVICE with the exact primitive the trace kernel uses (host pointers):

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -161,6 +161,8 @@ PROTOTYPES = {
     "kr_reduce_return_f64": (_int, [P(ReturnBins), _vp, _i64, P(_dbl * 4)]),
     "kr_reduce_return_dev_f64": (_int, [P(ReturnBins), _vp, _i64, _vp, _vp]),
     "kr_post_return_dev_f64": (_int, [_dbl, _dbl, P(ReturnBins), _vp, _i64, _vp, _vp]),
+    "kr_post_return_batch_dev_f64": (_int, [_i32, _dbl, _dbl, P(ReturnBins), P(_vp), P(_i64), P(_vp), _vp]),
+    "kr_pointsource_init_emit_batch_dev_f64": (_int, [_i32, P(PointSourceSpec), P(_dbl), _int, _int, P(_vp), P(_i64), _vp]),
     "kr_debug_arith_f64": (_int, [_int, _vp, _vp, _vp, _i64]),
     "kr_host_attach": (_int, [_vp, _i64, _i32]),
     "kr_host_detach": (_int, [_vp]),

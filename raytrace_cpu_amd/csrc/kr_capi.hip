@@ -43,6 +43,8 @@ int pointsource_init_emit_dev(const kr_pointsource* s, void* d, int64_t n, int64
 int reduce_image_dev(const kr_image_bins* b, const void* d, int64_t n, void* d_planes, hipStream_t st);
 int reduce_return_dev(const kr_return_bins* b, const void* d, int64_t n, void* d_out4, hipStream_t st);
 int post_return_dev(double lo, double hi, const kr_return_bins* b, void* d, int64_t n, void* d_out4, hipStream_t st);
+int post_return_batch_dev(int count, double lo, double hi, const kr_return_bins* b, void* const* d, const int64_t* n, void* const* d_out4, hipStream_t st);
+int pointsource_init_emit_batch_dev(int count, const kr_pointsource* s, const double* V, int reverse, int projradius, void* const* d, const int64_t* n, hipStream_t st);
 int arith_probe_dev(int op, const double* a, const double* b, double* out, int64_t n);
 
 static thread_local std::string g_error;
@@ -525,6 +527,14 @@ int kr_pointsource_init_emit_dev_f64(const kr_pointsource* s, int64_t first, int
     int rc = require_device();
     return rc != KR_OK ? rc : pointsource_init_emit_dev(s, d, count, first, stride, V, reverse, projradius, (hipStream_t) st);
 }
+int kr_pointsource_init_emit_batch_dev_f64(int32_t count, const kr_pointsource* s, const double* V, int reverse, int projradius, void* const* d, const int64_t* n, void* st)
+{
+    if (count < 0 || (count > 0 && (!s || !d || !n))) { set_error("kr_pointsource_init_emit_batch: null argument"); return KR_EINVAL; }
+    for (int32_t i = 0; i < count; i++)
+        if (n[i] > 0 && !d[i]) { set_error("kr_pointsource_init_emit_batch: null ray buffer"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : pointsource_init_emit_batch_dev(count, s, V, reverse, projradius, d, n, (hipStream_t) st);
+}
 // ... and range_phi() + redshift() + the emissivity histogram in one pass
 int kr_post_emissivity_dev_f64(double spin, double V, int reverse, int projradius, int motion, double lo, double hi, const kr_emis_bins* b, void* d, int64_t n,
                                void* d_hist, void* st)
@@ -670,6 +680,15 @@ int kr_post_return_dev_f64(double lo, double hi, const kr_return_bins* b, void* 
     if (!b || !d_out4) { set_error("kr_post_return: null argument"); return KR_EINVAL; }
     int rc = require_device();
     return rc != KR_OK ? rc : post_return_dev(lo, hi, b, d, n, d_out4, (hipStream_t) st);
+}
+
+int kr_post_return_batch_dev_f64(int32_t count, double lo, double hi, const kr_return_bins* b, void* const* d, const int64_t* n, void* const* d_out4, void* st)
+{
+    if (count < 0 || (count > 0 && (!b || !d || !n || !d_out4))) { set_error("kr_post_return_batch: null argument"); return KR_EINVAL; }
+    for (int32_t i = 0; i < count; i++)
+        if (n[i] > 0 && (!d[i] || !d_out4[i])) { set_error("kr_post_return_batch: null buffer"); return KR_EINVAL; }
+    int rc = require_device();
+    return rc != KR_OK ? rc : post_return_batch_dev(count, lo, hi, b, d, n, d_out4, (hipStream_t) st);
 }
 
 int kr_reduce_return_f64(const kr_return_bins* b, const kr_ray_f64* rays, int64_t n, double out[4])

@@ -130,6 +130,40 @@ pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_poin
     }
 }
 
+// The same for SEVERAL sources in one launch (kr_pointsource_init_emit_batch_dev_f64: the multi-radius drivers).  A hundred launches of 1e6 rays
+// each cannot fill the GPU one at a time (0.093 ms per launch = 1.5 TB/s of stores against ~4 TB/s for one large launch, rocprofv3 r03); the
+// items of a chunk ride in the kernel arguments (no staging buffer whose lifetime a later call would have to track), blockIdx.y picks the item.
+struct SourceItem {
+    kr_pointsource s;
+    double V;
+    kr_ray_f64* rays;
+    long long n;
+    int n_cosalpha, n_beta;
+};
+constexpr int kSourceChunk = 24;                       // 24 x 160 B of the 4 KB a kernel's arguments may take
+struct SourceChunk { SourceItem item[kSourceChunk]; };
+
+__global__ void __launch_bounds__(kBlock)
+pointsource_init_emit_multi_kernel(SourceChunk c, int reverse, int projradius)
+{
+    const SourceItem& it = c.item[blockIdx.y];
+    const kr_pointsource s = it.s;
+    const long long n = it.n, n_grid = (long long) it.n_cosalpha * it.n_beta;
+    const int n_beta = it.n_beta;
+    kr_ray_f64* __restrict__ rays = it.rays;
+    const double a = reverse ? -1 * s.spin : s.spin;
+    double V = it.V;
+    if (V == -1) {
+        const kr_ray_f64 r0 = pointsource_ray(s, n_grid, n_beta, 0);
+        V = keplerian_V<double>(a, r0.r, r0.theta, projradius != 0);
+    }
+    for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
+        kr_ray_f64 ray = pointsource_ray(s, n_grid, n_beta, slot);
+        ray.emit = emit_value(ray, s.spin, a, V, reverse);
+        rays[slot] = ray;
+    }
+}
+
 // ---- ImagePlane ctor + init_image_plane (imageplane.cpp:11-121) ---------------------------------------------
 KR_DEV kr_ray_f64 imageplane_ray(const kr_imageplane& s, long long n_grid, int Ny, double a, double D, double incl, double phi0, long long ix)
 {
@@ -356,8 +390,7 @@ post_image_kernel(kr_ray_f64* __restrict__ rays, long long n, double spin, doubl
 // out4 = {ray_count, return, escape, lost}; per-wave shuffle reduction, one atomic per wave and word
 // FUSED: range_phi(lo, hi) first, in the same pass over the records (kr_post_return_dev_f64)
 template <bool FUSED>
-__global__ void __launch_bounds__(kBlock)
-reduce_return_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_return_bins b, double* __restrict__ out4, double lo, double hi)
+KR_DEV void reduce_return_body(kr_ray_f64* __restrict__ rays, long long n, const kr_return_bins& b, double* __restrict__ out4, double lo, double hi)
 {
     double acc[4] = {0, 0, 0, 0};
     for (long long i = blockIdx.x * (long long) kBlock + threadIdx.x; i < n; i += (long long) gridDim.x * kBlock) {
@@ -399,6 +432,31 @@ reduce_return_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_return_bins 
         for (int w = 0; w < kBlock / 64; w++) v += part[w][threadIdx.x];
         if (v != 0) atomicAdd(&out4[threadIdx.x], v);
     }
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kBlock)
+reduce_return_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_return_bins b, double* __restrict__ out4, double lo, double hi)
+{
+    reduce_return_body<FUSED>(rays, n, b, out4, lo, hi);
+}
+
+// several launches' reductions in one (kr_post_return_batch_dev_f64); items in the kernel arguments, blockIdx.y picks the item
+struct ReturnItem {
+    kr_return_bins b;
+    kr_ray_f64* rays;
+    long long n;
+    double* out4;
+};
+constexpr int kReturnChunk = 32;
+struct ReturnChunk { ReturnItem item[kReturnChunk]; };
+
+__global__ void __launch_bounds__(kBlock)
+reduce_return_multi_kernel(ReturnChunk c, double lo, double hi)
+{
+    const ReturnItem& it = c.item[blockIdx.y];
+    const kr_return_bins b = it.b;
+    reduce_return_body<true>(it.rays, it.n, b, it.out4, lo, hi);
 }
 
 // ---- diagnostics: the device arithmetic primitives the trace kernel is built from, exposed one at a time so that a
@@ -584,6 +642,51 @@ int post_return_dev(double lo, double hi, const kr_return_bins* b, void* d, int6
     if (n <= 0) return KR_OK;
     hipLaunchKernelGGL(reduce_return_kernel<true>, dim3(grid_for(n, 512)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *b, (double*) d_out4, lo, hi);
     KR_LAUNCH_CHECK();
+    return KR_OK;
+}
+
+int post_return_batch_dev(int count, double lo, double hi, const kr_return_bins* b, void* const* d, const int64_t* n, void* const* d_out4, hipStream_t st)
+{
+    static_assert(sizeof(ReturnChunk) <= 3840, "kernel arguments are limited to 4 KB");
+    for (int base = 0; base < count; base += kReturnChunk) {
+        ReturnChunk c;
+        std::memset(&c, 0, sizeof c);
+        int m = 0;
+        int64_t n_max = 0;
+        for (int i = base; i < count && i < base + kReturnChunk; i++) {
+            if (n[i] <= 0) continue;
+            c.item[m++] = ReturnItem{b[i], (kr_ray_f64*) d[i], (long long) n[i], (double*) d_out4[i]};
+            n_max = std::max(n_max, n[i]);
+        }
+        if (m == 0) continue;
+        // blocks per item: enough to keep ~16 waves per SIMD in flight over the whole chunk, never more than an item's rays need
+        const int per_item = (int) std::max<int64_t>(1, std::min<int64_t>((n_max + kBlock - 1) / kBlock, std::max(64, 8192 / m)));
+        hipLaunchKernelGGL(reduce_return_multi_kernel, dim3(per_item, m), dim3(kBlock), 0, st, c, lo, hi);
+        KR_LAUNCH_CHECK();
+    }
+    return KR_OK;
+}
+
+int pointsource_init_emit_batch_dev(int count, const kr_pointsource* s, const double* V, int reverse, int projradius, void* const* d, const int64_t* n, hipStream_t st)
+{
+    static_assert(sizeof(SourceChunk) <= 3968, "kernel arguments are limited to 4 KB");
+    for (int base = 0; base < count; base += kSourceChunk) {
+        SourceChunk c;
+        std::memset(&c, 0, sizeof c);
+        int m = 0;
+        int64_t n_max = 0;
+        for (int i = base; i < count && i < base + kSourceChunk; i++) {
+            if (n[i] <= 0) continue;
+            int32_t nc = 0, nb = 0;
+            kr_pointsource_count(&s[i], &nc, &nb);
+            c.item[m++] = SourceItem{s[i], V ? V[i] : s[i].V, (kr_ray_f64*) d[i], (long long) n[i], nc, nb};
+            n_max = std::max(n_max, n[i]);
+        }
+        if (m == 0) continue;
+        const int per_item = (int) std::max<int64_t>(1, std::min<int64_t>((n_max + kBlock - 1) / kBlock, std::max(64, 16384 / m)));
+        hipLaunchKernelGGL(pointsource_init_emit_multi_kernel, dim3(per_item, m), dim3(kBlock), 0, st, c, reverse, projradius);
+        KR_LAUNCH_CHECK();
+    }
     return KR_OK;
 }
 
