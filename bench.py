@@ -431,6 +431,7 @@ class ReturnRadiationWorkload:
         self.counts = [api.pointsource_count(s)[0] for s in self.specs]
         self.n = max(self.counts)
         self.nstreams, self.streams, self.buffers, self.order, self.ordered = max(0, args.streams), None, None, None, False
+        self.groups = max(1, int(getattr(args, "rr_groups", 4)))
         self.p = capi.default_params(SPIN)
         self.p.integrator, self.p.r_max = self.method, 1.1 * R_MAX
         if os.environ.get("KR_RR_BLOCKS"):                 # experiment: resident waves per SIMD of the merged main launch (scripts/gpu_euler_occ.sh)
@@ -440,7 +441,8 @@ class ReturnRadiationWorkload:
                          f"r_max=1.1*r_esc, per-radius relaunch (BASELINE configs[4])")
         self.pipeline = ("per radius: [pointsource_init+redshift_start]+trace+[range_phi+return_classification]; " +
                          (f"radii round-robin over {self.nstreams} stream(s), longest launches first, one counter read-back at the end" if self.nstreams else
-                          "all radii resident, traced by ONE merged batch (one side launch + one main launch over all radii)"))
+                          f"all radii resident, traced as {self.groups} merged batch(es) on streams of their own (one side launch + one main launch per batch; "
+                          "the O(N) passes of all radii of a batch in ceil(k / 24) + ceil(k / 32) launches)"))
         self.sharding = f"radii cyclic over {world} rank(s), " + ("fixed set of radii (strong scaling)" if args.scaling == "strong" else "radii added with the rank count (weak scaling)")
 
     def step(self, d_rays, d_res, stream):
@@ -511,6 +513,9 @@ class ReturnRadiationWorkload:
         t0.record(cur)
         # (the 100 source and 100 reducer kernels stay on this one stream: spread over 2 / 4 auxiliary streams the pass took 236 / 252 ms instead
         # of 233 -- streams that wait on the merged batch slow it down, profiles/r03_ab_experiments.txt)
+        groups = int(os.environ.get("KR_RR_GROUPS", self.groups))
+        if groups > 1 and len(self.specs) >= 2 * groups:
+            return self.step_grouped(d_res, stream, groups, cur, t0, t1)
         st_of = [stream] * len(self.specs)
         k = len(self.specs)
         if getattr(self, "batch_args", None) is None:
@@ -536,6 +541,45 @@ class ReturnRadiationWorkload:
         tot["kernel_ms"] = t0.elapsed_time(t1)
         return tot
 
+    def step_grouped(self, d_res, stream, groups, cur, t0, t1):
+        """The radii in G interleaved groups (--rr-groups, default 4), each a merged batch of its own on a stream of its own, so that one group's
+        memory-bound O(N) passes run beside another group's compute-bound trace: 100 radii x 1e6 rays 223.9 / 219.5 / 214.8-216.7 / 227 / 223 ms
+        with 1 / 2 / 4 / 5 / 8 groups (more groups: smaller merged launches, more side launches); the same sums to the last bits."""
+        import torch
+        lib, capi, vp = self.lib, self.capi, C.c_void_p
+        if getattr(self, "group_args", None) is None:
+            self.group_streams = [torch.cuda.Stream() for _ in range(groups)]
+            self.group_args = []
+            for g in range(groups):
+                idx = list(range(g, len(self.specs), groups))
+                k = len(idx)
+                specs = (capi.PointSourceSpec * k)(*[self.specs[j] for j in idx])
+                V = (C.c_double * k)(*[self.specs[j].V for j in idx])
+                ptrs = (C.c_void_p * k)(*[self.buffers[j].data_ptr() for j in idx])
+                ns = (C.c_int64 * k)(*[self.counts[j] for j in idx])
+                bins = (capi.ReturnBins * k)()
+                for q, j in enumerate(idx):
+                    b = bins[q]
+                    b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, self.radii[j][1], 1.5707
+                    b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
+                outs = (C.c_void_p * k)(*[d_res + 32 * self.radii[j][0] for j in idx])
+                self.group_args.append((idx, specs, V, ptrs, ns, bins, outs))
+        tickets = []
+        for g, (idx, specs, V, ptrs, ns, bins, outs) in enumerate(self.group_args):
+            gs = self.group_streams[g]
+            gs.wait_stream(cur)
+            k = len(idx)
+            capi.check(lib, lib.kr_pointsource_init_emit_batch_dev_f64(k, specs, V, 0, 0, ptrs, ns, vp(gs.cuda_stream)), "init")
+            tickets += self.api.trace_batch_async([self.p] * k, [self.buffers[j].data_ptr() for j in idx], [self.counts[j] for j in idx], [gs.cuda_stream] * k)
+            capi.check(lib, lib.kr_post_return_batch_dev_f64(k, -math.pi, math.pi, bins, ptrs, ns, outs, vp(gs.cuda_stream)), "post")
+        for gs in self.group_streams:
+            cur.wait_stream(gs)
+        t1.record(cur)
+        tot = self.api.trace_wait_many(tickets)
+        t1.synchronize()
+        tot["kernel_ms"] = t0.elapsed_time(t1)
+        return tot
+
     def summary(self, h):
         t = h.reshape(self.nr, 4)
         with np.errstate(invalid="ignore", divide="ignore"):
@@ -556,6 +600,8 @@ def main():
     ap.add_argument("--image-exchange", default="gather", choices=["gather", "allreduce"],
                     help="imageplane, N > 1: gather = pixel-column-cyclic shards, planes collected on rank 0; allreduce = ray-cyclic shards, planes summed everywhere")
     ap.add_argument("--no-overlap-exchange", action="store_true", help="N > 1: run the exchange on the compute stream instead of beside the next pass")
+    ap.add_argument("--rr-groups", type=int, default=4, help="return_radiation, --streams 0: the radii are traced as this many merged batches on streams of their own "
+                                                              "(one group's O(N) passes beside another's trace); 1 = one merged batch")
     ap.add_argument("--streams", type=int, default=0, help="return_radiation: HIP streams the per-radius launches are spread over (1 = serial relaunch; 0 = all radii resident, one merged batch)")
     ap.add_argument("--rays", type=float, default=0, help="rays per GPU (default: 1e7 emissivity = BASELINE configs[1]; 4097^2 imageplane = configs[3])")
     ap.add_argument("--integrator", default="rk4", choices=["euler", "rk4", "rk45"])

@@ -272,6 +272,14 @@ def test_return_radiation_full_size_properties(krlib):
     table0 = res.cpu().numpy().reshape(100, 4)
     assert st0["steps_total"] == st["steps_total"] and st0["rays_traced"] == st["rays_traced"]
     np.testing.assert_allclose(table0, table, rtol=1e-11)
+    assert wl0.groups == 4                                   # (the default: four merged batches on streams of their own, pipelined)
+    # ... and as ONE merged batch
+    wl0.groups = 1
+    res.zero_()
+    st0 = wl0.step(rays.data_ptr(), res.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert st0["steps_total"] == st["steps_total"] and st0["rays_traced"] == st["rays_traced"]
+    np.testing.assert_allclose(res.cpu().numpy().reshape(100, 4), table, rtol=1e-11)
     del wl0
     # one radius: shard additivity + sample vs oracle
     j = 37
