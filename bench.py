@@ -562,13 +562,13 @@ class ReturnRadiationWorkload:
                     b = bins[q]
                     b.r_isco, b.r_disc, b.r_esc, b.source_r, b.source_phi = self.r_isco, R_DISC, R_MAX, self.radii[j][1], 1.5707
                     b.plane_iso, b.limb, b.weight_norm, b.pad = 1, 0, 1, 0
-                outs = (C.c_void_p * k)(*[d_res + 32 * self.radii[j][0] for j in idx])
-                self.group_args.append((idx, specs, V, ptrs, ns, bins, outs))
+                self.group_args.append((idx, specs, V, ptrs, ns, bins))
         tickets = []
-        for g, (idx, specs, V, ptrs, ns, bins, outs) in enumerate(self.group_args):
+        for g, (idx, specs, V, ptrs, ns, bins) in enumerate(self.group_args):
             gs = self.group_streams[g]
             gs.wait_stream(cur)
             k = len(idx)
+            outs = (C.c_void_p * k)(*[d_res + 32 * self.radii[j][0] for j in idx])       # (the result table is double-buffered under torch.distributed: per call)
             capi.check(lib, lib.kr_pointsource_init_emit_batch_dev_f64(k, specs, V, 0, 0, ptrs, ns, vp(gs.cuda_stream)), "init")
             tickets += self.api.trace_batch_async([self.p] * k, [self.buffers[j].data_ptr() for j in idx], [self.counts[j] for j in idx], [gs.cuda_stream] * k)
             capi.check(lib, lib.kr_post_return_batch_dev_f64(k, -math.pi, math.pi, bins, ptrs, ns, outs, vp(gs.cuda_stream)), "post")

@@ -38,3 +38,28 @@ def test_bench_line_and_kernel_overlap_under_rccl():
     # serialised it would be their sum, ~2.2 x
     fast_ms = d["other_arithmetic_modes"]["fast"]["avg_kernel_ms"]
     assert roof["avg_kernel_ms"] < 1.6 * fast_ms, (roof["avg_kernel_ms"], fast_ms)
+
+
+def _bench_line(extra, env_extra=None):
+    env = dict(os.environ, **(env_extra or {}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast-math-extra"] + extra,
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_returning_radiation_line_is_the_same_with_and_without_the_collective_path():
+    """The grouped, pipelined returning-radiation pass writes into whichever of the two result tables the pass was given (under torch.distributed
+    the table is double-buffered for the exchange beside the next pass): the fractions of the last pass are finite and the same either way."""
+    args = ["--workload", "return_radiation", "--radii", "12", "--rays", "2e5"]
+    plain = _bench_line(args)
+    dist = _bench_line(args, dict(KR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29562", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    single = _bench_line(args + ["--rr-groups", "1"])
+    for key, want in plain["fractions_escape_return_lost"].items():
+        for other in (dist, single):
+            got = other["fractions_escape_return_lost"][key]
+            assert all(abs(g - w) <= 1e-12 and g == g for g, w in zip(got, want)), (key, got, want)
+    assert dist["rccl_ranks"] == 1 and plain["rccl_ranks"] is None
+    assert dist["rk_steps_per_launch"] == plain["rk_steps_per_launch"] == single["rk_steps_per_launch"]
