@@ -63,3 +63,18 @@ def test_returning_radiation_line_is_the_same_with_and_without_the_collective_pa
             assert all(abs(g - w) <= 1e-12 and g == g for g, w in zip(got, want)), (key, got, want)
     assert dist["rccl_ranks"] == 1 and plain["rccl_ranks"] is None
     assert dist["rk_steps_per_launch"] == plain["rk_steps_per_launch"] == single["rk_steps_per_launch"]
+
+
+@pytest.mark.parametrize("extra,keys", [(["--workload", "emissivity", "--rays", "3e5"], ("disc_hits",)),
+                                        (["--workload", "imageplane", "--rays", "2e5"], ("disc_hits", "lit_pixels")),
+                                        (["--workload", "imageplane", "--rays", "2e5", "--image-exchange", "allreduce"], ("disc_hits", "lit_pixels")),
+                                        (["--workload", "emissivity", "--rays", "3e5", "--scaling", "strong"], ("disc_hits",))],
+                         ids=["emissivity", "imageplane-gather", "imageplane-allreduce", "emissivity-strong"])
+def test_summaries_agree_with_and_without_the_collective_path(extra, keys):
+    """What the last pass left in the (double-buffered, exchanged-beside-the-next-pass) result buffer under torch.distributed with one rank is
+    what the plain run leaves: disc-hit counts and lit pixels are exact counts."""
+    plain = _bench_line(extra)
+    dist = _bench_line(extra, dict(KR_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29563", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    for k in keys:
+        assert plain[k] == dist[k] and plain[k] > 0, (k, plain[k], dist[k])
+    assert dist["rccl_ranks"] == 1 and dist["rk_steps_per_launch"] == plain["rk_steps_per_launch"]
