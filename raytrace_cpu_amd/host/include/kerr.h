@@ -19,6 +19,7 @@ template <typename T>
 struct BLCoefficients {
     T rhosq, delta, sigmasq, e2nu, e2psi, omega;
 
+    BLCoefficients() = default;       // (filled in by a caller whose spin has another type than T: raytracer/image_ray.h)
     BLCoefficients(T r, T theta, T a)
     {
         using std::cos;

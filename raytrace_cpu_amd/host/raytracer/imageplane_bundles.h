@@ -15,6 +15,7 @@
 
 #include "ray_destination.h"
 #include "raytracer.h"
+#include "image_ray.h"
 
 template <typename T>
 class ImagePlaneBundles : public Raytracer<T> {
@@ -66,52 +67,21 @@ private:
     T plane_dist, plane_incl, plane_phi0;
     T origin_x, origin_y, pitch;
 
-    // one ray through image-plane point (x, y): position, line-of-sight momentum, null condition, impact-parameter constants
+    // one ray through image-plane point (x, y): krhost::camera_ray with this class's conventions (spin in T, the centre point guarded)
     void place_ray(int ix, T x, T y)
     {
         const T a = Raytracer<T>::spin;
-        const T D = plane_dist, incl = plane_incl;
+        const krhost::CameraRay<T> c = krhost::camera_ray<T, T, false, true>(plane_dist, plane_incl, plane_phi0, x, y, a);
         Ray<T>& R = Raytracer<T>::rays[ix];
-
-        const T r = sqrt(D * D + x * x + y * y);
-        const T theta = acos((D * cos(incl) + y * sin(incl)) / r);
-        const T phi = plane_phi0 + atan2(x, D * sin(incl) - y * cos(incl));
-        const T pr = D / r;
-        const T ptheta = sin(acos(D / r)) / r;
-        const T pphi = x * sin(incl) / (x * x + (D * sin(incl) - y * cos(incl)) * (D * sin(incl) - y * cos(incl)));
-
-        const krhost::BLCoefficients<T> m(r, theta, a);
-        const T g00 = m.e2nu - m.omega * m.omega * m.e2psi;
-        const T g03 = m.omega * m.e2psi;
-        const T g11 = -m.rhosq / m.delta;
-        const T g22 = -m.rhosq;
-        const T g33 = -m.e2psi;
-        const T A = g00;
-        const T B = 2 * g03 * pphi;
-        const T C = g11 * pr * pr + g22 * ptheta * ptheta + g33 * pphi * pphi;
-        T pt = (-B + sqrt(B * B - 4 * A * C)) / (2 * A);
-        if (pt < 0) pt = (-B - sqrt(B * B - 4 * A * C)) / (2 * A);
-
         R.t = 0;
-        R.r = r;
-        R.theta = theta;
-        R.phi = phi;
-        R.pt = pt;
-        R.pr = pr;
-        R.ptheta = ptheta;
-        R.pphi = pphi;
-        Raytracer<T>::calculate_constants_from_p(ix, pt, pr, ptheta, pphi);
+        R.r = c.r; R.theta = c.theta; R.phi = c.phi;
+        R.pt = c.pt; R.pr = c.pr; R.ptheta = c.ptheta; R.pphi = c.pphi;
+        Raytracer<T>::calculate_constants_from_p(ix, c.pt, c.pr, c.ptheta, c.pphi);
         R.rdot_sign = -1;
         R.k = 1;
-
-        const T b = sqrt(x * x + y * y);
-        T beta_ang = (b > 0) ? asin(y / b) : 0;
-        if (x < 0) beta_ang = M_PI - beta_ang;
-        const T h = -b * sin(incl) * cos(beta_ang);
-        const T ltheta = b * sin(beta_ang);
-        R.h = h;
-        R.Q = ltheta * ltheta - (a * cos(theta)) * (a * cos(theta)) + (h / tan(theta)) * (h / tan(theta));
-        R.thetadot_sign = (ltheta >= 0) ? 1 : -1;
+        R.h = c.h;
+        R.Q = c.Q;
+        R.thetadot_sign = c.thetadot_sign;
         R.steps = 0;
         R.alpha = x;
         R.beta = y;

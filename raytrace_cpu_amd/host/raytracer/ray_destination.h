@@ -16,6 +16,7 @@
 #include <limits>
 
 #include "../../../include/kr_trace.h"
+#include "../include/kerr.h"
 
 template <typename T>
 class RayDestination {
@@ -34,22 +35,16 @@ public:
     // contravariant Boyer-Lindquist 4-velocity {ut, ur, utheta, uphi} of the material (circular motion at velocity())
     virtual void four_velocity(T r, T theta, T phi, T spin, T et[4]) const
     {
-        using std::cos;
-        using std::sin;
         using std::sqrt;
         T V = velocity(r, theta, phi);
-        const T rhosq = r * r + (spin * cos(theta)) * (spin * cos(theta));
-        const T delta = r * r - 2 * r + spin * spin;
-        const T sigmasq = (r * r + spin * spin) * (r * r + spin * spin) - spin * spin * delta * sin(theta) * sin(theta);
-        const T e2nu = rhosq * delta / sigmasq;
-        const T e2psi = sigmasq * sin(theta) * sin(theta) / rhosq;
-        const T omega = 2 * spin * r / sigmasq;
-        if (V == -1) V = 1 / (spin + r * sqrt(r));
-        const T gamma_factor = 1 / sqrt(1 - (V - omega) * (V - omega) * e2psi / e2nu);
-        et[0] = gamma_factor / sqrt(e2nu);
+        if (V == -1) V = 1 / (spin + r * sqrt(r));                 // equatorial Keplerian
+        // u = (ut, 0, 0, V ut) normalised in the frame of the zero-angular-momentum observer: relative angular velocity V - omega
+        const krhost::BLCoefficients<T> m(r, theta, spin);
+        const T lorentz = 1 / sqrt(1 - (V - m.omega) * (V - m.omega) * m.e2psi / m.e2nu);
+        et[0] = lorentz / sqrt(m.e2nu);
         et[1] = 0;
         et[2] = 0;
-        et[3] = gamma_factor * V / sqrt(e2nu);
+        et[3] = lorentz * V / sqrt(m.e2nu);
     }
 
     // POD description for the device path: fills stop_kind (KR_STOP_*) and stop_params[4]; false if this
