@@ -18,28 +18,27 @@ template <typename T>
 void PointSource<T>::init_pointsource(T* pos, T dcosalpha, T dbeta, T cosalpha0, T cosalphamax, T beta0, T betamax)
 {
     Ray<T>* rays = Raytracer<T>::rays;
-    // every slot is a pure function of (i, j): rows are shared among the host threads (the reference's loop is serial;
-    // at 1e7 rays it costs more than the whole GPU trace)
+    // Slot ix = i * n_beta + j of the array is the ray in direction (cos(alpha), beta) = (cosalpha0 + i dcosalpha, beta0 + j dbeta) when that point
+    // lies inside the half-open ranges, and an unused slot (steps = -1, as the base constructor left it) otherwise.  Every slot is a pure
+    // function of its index, so the slots -- not the rows -- are shared among the host threads (the reference's double loop is serial; at 1e7 rays
+    // it costs more than the whole GPU trace).
+    const long n_slots = static_cast<long>(n_cosalpha) * n_beta;
 #pragma omp parallel for schedule(static) num_threads(kr_host_threads())
-    for (int i = 0; i < n_cosalpha; i++) {
+    for (long ix = 0; ix < n_slots; ix++) {
+        const int i = static_cast<int>(ix / n_beta), j = static_cast<int>(ix % n_beta);
         const T cosalpha = cosalpha0 + i * dcosalpha;
-        for (int j = 0; j < n_beta; j++) {
-            Ray<T>& R = rays[i * n_beta + j];
-            const T beta = beta0 + j * dbeta;
-            if (cosalpha >= cosalphamax || beta >= betamax) {   // outside the half-open ranges: slot stays unused
-                R.steps = -1;
-                continue;
-            }
-            R.alpha = cosalpha;     // the reference stores cos(alpha) in `alpha` (:48); consumers depend on it
-            R.beta = beta;
-            R.t = pos[0];
-            R.r = pos[1];
-            R.theta = pos[2];
-            R.phi = pos[3];
-            R.pt = R.pr = R.ptheta = R.pphi = 0;
-            R.steps = 0;
-            Raytracer<T>::calculate_constants(i * n_beta + j, acos(cosalpha), beta, velocity, energy);
+        const T beta = beta0 + j * dbeta;
+        Ray<T>& R = rays[ix];
+        if (cosalpha >= cosalphamax || beta >= betamax) {
+            R.steps = -1;
+            continue;
         }
+        R.t = pos[0]; R.r = pos[1]; R.theta = pos[2]; R.phi = pos[3];      // every ray starts at the source's event
+        R.pt = R.pr = R.ptheta = R.pphi = 0;
+        R.alpha = cosalpha;     // sic: the reference keeps cos(alpha) in `alpha` (:48); consumers depend on it
+        R.beta = beta;
+        R.steps = 0;
+        Raytracer<T>::calculate_constants(static_cast<int>(ix), acos(cosalpha), beta, velocity, energy);
     }
 }
 
