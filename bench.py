@@ -277,9 +277,7 @@ class EmissivityWorkload:
         self.describe = (f"PointSource emissivity lamp-post h=10 a=0.998 V=0, {args.integrator.upper()}, theta_max=pi/2 r_max=1000 "
                          f"(BASELINE configs[1]); grid {self.n_ca}x{self.n_b} per GPU")
         self.fused = not args.separate_passes
-        self.in_kernel = getattr(args, "pipeline", "passes") == "kernel"
-        self.pipeline = ("ONE trace kernel: pointsource_init+redshift_start in its load path, redshift+emissivity_histogram (LDS) in its store path -- no ray records in HBM" if self.in_kernel else
-                         "[pointsource_init+redshift_start]+trace+[range_phi+redshift+emissivity_histogram] ([..] = one fused pass each)" if self.fused
+        self.pipeline = ("[pointsource_init+redshift_start]+trace+[range_phi+redshift+emissivity_histogram] ([..] = one fused pass each)" if self.fused
                          else "pointsource_init+redshift_start+trace+range_phi+redshift+emissivity_histogram")
         self.sharding = f"row-cyclic over {world} rank(s), " + ("fixed global grid (strong scaling)" if strong else "grid refined with the rank count (weak scaling)")
         self.scaling = args.scaling
@@ -287,11 +285,6 @@ class EmissivityWorkload:
     def step(self, d_rays, d_res, stream):
         lib, capi, vp = self.lib, self.capi, C.c_void_p
         n = self.n
-        if self.in_kernel:   # the whole pipeline as ONE trace: rays built in the kernel's load path, binned in its store path -- no ray records at all
-            st = capi.Stats()
-            capi.check(lib, lib.kr_emissivity_pipeline_dev_f64(C.byref(self.spec), 0, 1, n, 0.0, 0, 0, C.byref(self.p), SPIN, -1.0, 0, 0, 0, C.byref(self.bins),
-                                                               vp(d_res), vp(stream), C.byref(st)), "emissivity pipeline")
-            return st.as_dict()
         if self.fused:      # same per-ray arithmetic, two passes over the records instead of five (tests: test_fused_pipeline_ends_...)
             capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(self.spec), 0, 1, 0.0, 0, 0, vp(d_rays), n, vp(stream)), "init_emit")
             st = self.api.trace_dev(self.p, d_rays, n, stream=stream, want_stats=True)
@@ -609,9 +602,6 @@ def main():
                     help="hybrid (KR_FLAG_HYBRID: strict for ill-conditioned rays, fast for the rest), strict (flags = 0), fast (KR_FLAG_FAST_MATH); "
                          "auto = hybrid for euler / rk4, strict for rk45 (what the host mirror of the class API does)")
     ap.add_argument("--fast-math", action="store_true", help="same as --arithmetic fast")
-    ap.add_argument("--pipeline", default="passes", choices=["passes", "kernel"],
-                    help="emissivity: passes = source pass + trace + reducer pass over 144-B ray records in HBM; kernel = kr_emissivity_pipeline_dev_f64, "
-                         "rays generated and binned inside the trace kernel (no ray records)")
     ap.add_argument("--separate-passes", action="store_true", help="emissivity / imageplane: the five O(N) passes one kernel each instead of the two fused ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-math-extra", action="store_true")

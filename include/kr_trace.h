@@ -311,15 +311,6 @@ int kr_pointsource_init_emit_dev_f64(const kr_pointsource* s, int64_t first, int
  * s, V (may be NULL), d_rays and n are HOST arrays of `count` entries, read before the call returns. */
 int kr_pointsource_init_emit_batch_dev_f64(int32_t count, const kr_pointsource* s, const double* V, int reverse, int projradius, void* const* d_rays, const int64_t* n,
                                            void* stream);
-/* The emissivity pipeline of src/emissivity/emissivity.cpp:60-126 -- PointSource ctor, redshift_start(V_start, ...), run_raytrace(theta_max, r_max),
- * redshift(V, ...), radial histogram -- as ONE trace whose rays never exist in memory: a lane builds source ray `first + slot * stride` in
- * registers when it takes slot `slot` (0 <= slot < count) off the work queue and adds the finished ray to the histogram (LDS per workgroup,
- * one global atomic per non-empty word on exit).  Same per-ray functions as kr_pointsource_init_emit_dev_f64 + kr_trace_dev_f64 +
- * kr_post_emissivity_dev_f64, so counts are identical and sums differ only in the order of addition.  p: the trace's parameters (theta-limit
- * overload; flags as for kr_trace_*); d_hist: 5 nr + 1 doubles, ADDED to (zero it first); stats may be null (then the call does not wait). */
-int kr_emissivity_pipeline_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, int64_t count, double V_start, int32_t reverse_start,
-                                   int32_t projradius_start, const kr_params* p, double spin, double V, int32_t reverse, int32_t projradius, int32_t motion,
-                                   const kr_emis_bins* bins, void* d_hist, void* stream, kr_stats* stats);
 /* the same for the image pipeline: ImagePlane ctor + redshift_start(V, reverse, projradius) (imageplane.cpp:11-121; the negated spin
  * of the ImagePlane is applied inside), and redshift(V, reverse, projradius, motion) + range_phi(lo, hi) + the seven planes of
  * kr_reduce_image_dev_f64 (imageplane_disc_image.cpp:117-161; `spin` as stored by the Raytracer, i.e. negated) */

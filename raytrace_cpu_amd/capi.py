@@ -155,7 +155,6 @@ PROTOTYPES = {
     "kr_imageplane_init_emit_runs_dev_f64": (_int, [P(ImagePlaneSpec), _i64, _i64, _i64, _dbl, _int, _int, _vp, _i64, _vp]),
     "kr_post_image_dev_f64": (_int, [_dbl, _dbl, _int, _int, _int, _dbl, _dbl, P(ImageBins), _vp, _i64, _vp, _vp]),
     "kr_post_emissivity_dev_f64": (_int, [_dbl, _dbl, _int, _int, _int, _dbl, _dbl, P(EmisBins), _vp, _i64, _vp, _vp]),
-    "kr_emissivity_pipeline_dev_f64": (_int, [P(PointSourceSpec), _i64, _i64, _i64, _dbl, _i32, _i32, P(Params), _dbl, _dbl, _i32, _i32, _i32, P(EmisBins), _vp, _vp, P(Stats)]),
     "kr_reduce_image_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
     "kr_reduce_image_dev_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp]),
     "kr_reduce_return_f64": (_int, [P(ReturnBins), _vp, _i64, P(_dbl * 4)]),

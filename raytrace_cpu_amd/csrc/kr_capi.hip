@@ -543,29 +543,6 @@ int kr_post_emissivity_dev_f64(double spin, double V, int reverse, int projradiu
     int rc = require_device();
     return rc != KR_OK ? rc : post_emissivity_dev(spin, V, reverse, projradius, motion, lo, hi, b, d, n, d_hist, (hipStream_t) st);
 }
-// ... and the whole emissivity pipeline as ONE trace whose rays never exist in memory
-int kr_emissivity_pipeline_dev_f64(const kr_pointsource* s, int64_t first, int64_t stride, int64_t count, double V_start, int reverse_start, int projradius_start,
-                                   const kr_params* p, double spin, double V, int reverse, int projradius, int motion, const kr_emis_bins* b, void* d_hist, void* st,
-                                   kr_stats* stats)
-{
-    if (!s || !p || !b || !d_hist) { set_error("kr_emissivity_pipeline: null argument"); return KR_EINVAL; }
-    if (first < 0 || stride < 1 || count < 0) { set_error("kr_emissivity_pipeline: bad first / stride / count"); return KR_EINVAL; }
-    if (b->nr <= 0) { set_error("kr_emissivity_pipeline: nr must be positive"); return KR_EINVAL; }
-    int rc = require_device();
-    if (rc != KR_OK) return rc;
-    int32_t nc = 0, nb = 0;
-    kr_pointsource_count(s, &nc, &nb);
-    EmisPipeArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.src = *s;
-    a.n_grid = (long long) nc * nb; a.n_beta = nb; a.first = first; a.stride = stride;
-    a.V_start = V_start; a.reverse_start = reverse_start; a.projradius_start = projradius_start;
-    a.spin = spin; a.V = V; a.reverse = reverse; a.projradius = projradius; a.motion = motion;
-    a.bins = *b;
-    a.hist = (double*) d_hist;
-    a.use_lds = b->nr <= 256;              // 5 nr + 1 doubles per single-wave workgroup: 10 KB at most, 12 workgroups per CU
-    return trace_pipeline_emis(p, &a, count, (hipStream_t) st, stats);
-}
 int kr_imageplane_init_emit_dev_f64(const kr_imageplane* s, int64_t first, int64_t stride, double V, int reverse, int projradius, void* d, int64_t count, void* st)
 {
     if (!s) { set_error("kr_imageplane_init_emit: null spec"); return KR_EINVAL; }

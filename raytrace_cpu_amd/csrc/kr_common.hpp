@@ -36,7 +36,5 @@ int trace_wait(void* ticket, kr_stats* stats);
 void trace_release(void* ticket);
 void side_stream_forget(hipStream_t user);
 int trace_shutdown();
-struct EmisPipeArgs;
-int trace_pipeline_emis(const kr_params* p, const EmisPipeArgs* args, int64_t n, hipStream_t stream, kr_stats* stats);
 
 }  // namespace kr

@@ -1,7 +1,6 @@
 // kr_post_device.hpp -- the per-ray device functions of the O(N) passes either side of the trace (ray sources, redshift_start, redshift,
-// range_phi, the emissivity reducer's accumulation): shared by the streaming kernels of kr_post.hip, which apply them to 144-byte records in
-// HBM, and by the pipeline instances of the trace kernel (kr_trace.hip), which apply them in the kernel's load and store paths so that no ray
-// record exists in memory at all.  One definition each, so both routes produce the same per-ray bits.  Reference lines cited per function.
+// range_phi, the emissivity reducer's accumulation), applied by the streaming kernels of kr_post.hip to 144-byte records in HBM; the fused and the
+// separate passes share one definition each, so both routes produce the same per-ray bits.  Reference lines cited per function.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -197,21 +196,5 @@ KR_DEV void emissivity_accumulate(double* acc, const kr_emis_bins& b, double log
         atomicAdd(&acc[5 * nr], 1.0);
     }
 }
-
-
-// everything the emissivity pipeline's load and store paths need besides the trace's own constants (kr_trace.hip: EmisPipeIO, trace_pipe_kernel)
-struct EmisPipeArgs {
-    kr_pointsource src;
-    long long n_grid, first, stride;
-    int n_beta;
-    double V_start;             // redshift_start(V, reverse, projradius)
-    int reverse_start, projradius_start;
-    double spin, V;             // redshift(V, reverse, projradius, motion) after the trace
-    int reverse, projradius, motion;
-    kr_emis_bins bins;
-    double* hist;               // 5 nr + 1 doubles in device memory
-    int use_lds;                // the histogram fits the workgroup's LDS allocation (else: global atomics per ray)
-};
-
 
 }  // namespace kr

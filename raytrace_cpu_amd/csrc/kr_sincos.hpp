@@ -9,35 +9,13 @@
 #define KR_SC_FN static inline
 #endif
 
-#ifndef KR_COMPACT_SINCOS
-#define KR_COMPACT_SINCOS 1
-#endif
-
-// Polynomial coefficients as scalar-register operands.  gfx950 has no 64-bit literals: the compiler's default for fma(z, p, C) is
-// v_fmac_f64 with C copied into the destination VGPR pair first -- two v_mov_b32 per coefficient, i.e. three vector instructions
-// per Horner step, ~50 extra VALU instructions per RK4 step of a kernel that is VALU-issue bound.  Passing the constant through
-// an empty asm with an "s" constraint pins it to an SGPR pair (s_mov_b32 x2 on the scalar unit, which runs beside the vector
-// unit) and the step becomes one v_fma_f64 v, v, v, s[..].  Same value, same rounding.
-// MEASURED AND REJECTED (default off): the fast RK4 kernel loses 38 v_mov per step and its 12 spilled VGPRs, but gains 40 spilled
-// SGPRs whose reloads (v_readlane) sit in the step loop: 94.1 ms against 92.7 ms (1e7 rays; profiles/r02_ab_experiments.txt).
-// The blanket alternative -- building without v_fmac_f64 (-target-feature -fmacf64-inst) -- loses the same way (93.2 vs 90.8 ms).
-#ifndef KR_SGPR_COEFFS
-#define KR_SGPR_COEFFS 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && KR_SGPR_COEFFS
-static __device__ __forceinline__ double kr_sconst(double c) { asm volatile("" : "+s"(c)); return c; }
-#define KR_K(x) kr_sconst(x)
-#else
-#define KR_K(x) (x)
-#endif
 // Horner step p <- fma(z, p, C) as ONE vector instruction.  The compiler keeps the coefficients C resident in VGPR pairs across the
 // step loop (good) but then emits the destructive two-operand form, v_mov_b64 tmp, C + v_fmac_f64 tmp, z, p -- two vector
 // instructions per polynomial step, ~40 per RK4 step of the fast kernel.  Spelling the three-operand v_fma_f64 out keeps C where it is.
 // Same operation, same rounding.
-#ifndef KR_ASM_FMA
-#define KR_ASM_FMA 1
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && KR_ASM_FMA
+// (Measured and rejected, profiles/r02_ab_experiments.txt: pinning every coefficient to an SGPR pair, or building without v_fmac_f64 -- the SGPR
+// spills that follow are reloaded by v_readlane inside the step loop: 94.1 / 93.2 ms against 92.7 / 90.8.)
+#if defined(__HIP_DEVICE_COMPILE__)
 static __device__ __forceinline__ double kr_fma3(double a, double b, double c)
 {
     double r;
@@ -49,7 +27,7 @@ static __device__ __forceinline__ double kr_fma3(double a, double b, double c)
 #endif
 // the same with the addend in a SCALAR register pair (one SGPR operand is allowed per VALU instruction): for constants that are only live
 // for part of a step, so that they need neither a VGPR pair nor a v_mov_b64 to materialise them (kr_device.hpp::sincos_near)
-#if defined(__HIP_DEVICE_COMPILE__) && KR_ASM_FMA
+#if defined(__HIP_DEVICE_COMPILE__)
 static __device__ __forceinline__ double kr_fma3s(double a, double b, double c)
 {
     double r;
@@ -60,24 +38,14 @@ static __device__ __forceinline__ double kr_fma3s(double a, double b, double c)
 #define kr_fma3s(a, b, c) __builtin_fma((a), (b), (c))
 #endif
 
-#ifndef KR_SGPR_COEFFS_STRICT
-#define KR_SGPR_COEFFS_STRICT 1
-#endif
-#if KR_SGPR_COEFFS_STRICT
-#define KR_KS(x) KR_K(x)          /* the strict-path routines (kr_sincos_general_f64, kr_sincos_small_f64) */
-#else
-#define KR_KS(x) (x)
-#endif
-
 // sin and cos of a polar angle.  theta stays within a few multiples of pi (it is reflected back into [0, pi]
 // after every step and the RK stages move it by a fraction of that), so the general-purpose device sincos
 // (Payne-Hanek capable, ~90 VALU instructions, 4 calls per RK4 step = a third of the step) is replaced by:
 //   n = rint(x * 2/pi);  r = x - n*pi/2 in two FMA steps (pi/2 = P1 + P2, the first one exact for |n| < 2^10:
 //   x and n*P1 are multiples of ulp(P1) and |r| < 1), with the rounding tail of the second step kept;
-//   sin/cos of r in [-pi/4, pi/4] from the classic degree-13 / degree-14 minimax kernels with tail
-//   correction (Sun fdlibm k_sin.c / k_cos.c coefficients; < 1 ulp); quadrant fix-up by n mod 4.
-// About 45 instructions for both results.  |x| >= 1024 (never reached by a healthy ray) and non-finite inputs
-// take the library path.
+//   sin/cos of r in [-pi/4, pi/4] from kr_sincos_cr_core_f64 below (strict callers) or plain Horner kernels (the fast
+//   arithmetic, kr_sincos_fast_f64); quadrant fix-up by n mod 4.
+// |x| >= 1024 (never reached by a healthy ray) and non-finite inputs take the library path.
 //
 // Small polar angles (|x| < 2^-7) take a branch of their own, kr_sincos_small_f64: no reduction (n = 0, r = x exactly), no
 // quadrant logic, Taylor kernels x + x z (S1 + z (S2 + z S3)) and 1 + (z^2 (C2 + z C3) - z/2) with z = x^2 < 6.2e-5: the first
@@ -87,54 +55,45 @@ static __device__ __forceinline__ double kr_fma3s(double a, double b, double c)
 // for 3e4 steps, 1e5 under RK45) are the longest rays of a launch, and a launch cannot end before its longest ray does.
 // The choice is a pure function of x, so a ray gets the same bits in whichever kernel / wave it is traced; on the device the
 // branch is taken wave-uniformly (all lanes small -> only the short kernel; mixed wave -> both and a select).
-#ifndef KR_SMALL_ANGLE_SINCOS
-#define KR_SMALL_ANGLE_SINCOS 1
-#endif
 #define KR_SMALL_ANGLE_LIMIT 0.0078125      /* 2^-7 */
 KR_SC_FN void kr_sincos_small_f64(double x, double& s, double& c)
 {
     const double z = x * x;
-    const double ps = kr_fma3(z, kr_fma3(z, KR_KS(-1.98412698412698412698e-04), KR_KS(8.33333333333333333333e-03)), KR_KS(-1.66666666666666666667e-01));
+    const double ps = kr_fma3(z, kr_fma3(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03), -1.66666666666666666667e-01);
     s = __builtin_fma(x * z, ps, x);
-    const double pc = kr_fma3(z, KR_KS(-1.38888888888888888889e-03), KR_KS(4.16666666666666666667e-02));
+    const double pc = kr_fma3(z, -1.38888888888888888889e-03, 4.16666666666666666667e-02);
     c = 1.0 + __builtin_fma(z * z, pc, -0.5 * z);
 }
 
-template <bool CR> KR_SC_FN void kr_sincos_general_t(double x, double& s, double& c);
+KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c);
 
 // |x| >= 1024 and non-finite arguments (never reached by a healthy ray): the library routine, OUT OF LINE.  Inlined it is ~1 KB of
 // Payne-Hanek code per call site -- 9 KB of the RK45 kernels, 4 KB of the RK4 ones -- and the instruction cache (64 KB per two CUs)
 // is what a lone strict wave and the main launch's waves on the same CUs compete for.
-#ifndef KR_LIBM_OUT_OF_LINE
-#define KR_LIBM_OUT_OF_LINE 1
-#endif
-#if defined(__HIPCC__) && KR_LIBM_OUT_OF_LINE
+#if defined(__HIPCC__)
 static __device__ __attribute__((noinline)) void kr_sincos_libm_f64(double x, double* s, double* c) { sincos(x, s, c); }
 #else
 KR_SC_FN void kr_sincos_libm_f64(double x, double* s, double* c) { sincos(x, s, c); }
 #endif
 
-// Correctly rounded in practice (KR_CR_SINCOS, default): sin and cos of the reduced argument r + y, |r| <= pi/4, with the leading
+// Correctly rounded in practice: sin and cos of the reduced argument r + y, |r| <= pi/4, with the leading
 // terms carried in double-double -- r^3 (S1 + z (S2 + ...)) and z^2 (C2 + z (C3 + ...)) with z = r^2 as an exact product, S1, S2, C2, C3
 // as (hi, lo) pairs, Taylor tails (through r^21 / z^10) in plain double -- and ONE final rounding.  The accumulated error before that
 // rounding is ~2^-66 of the result: 12e6 random arguments in (-40, 40) all come out correctly rounded (against __float128), which makes
 // the strict path differ from glibc only where glibc itself is not correctly rounded (0.01-0.26 % of arguments; the fdlibm kernels
 // this replaces: 3-5 %).  ~95 fp64 instructions for the pair instead of ~68: the TwoSum / TwoProd sequences below rely on
 // -ffp-contract=off (every fma is spelled out).
-#ifndef KR_CR_SINCOS
-#define KR_CR_SINCOS 1
-#endif
 KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
 {
     const double zh = r * r, zl = __builtin_fma(r, r, -zh);
     // sin(r + y) = r + y cos r + r^3 (S1 + z (S2 + z T(z)))
-    double T = kr_fma3(zh, KR_KS(1.9572941063391263e-20), KR_KS(-8.22063524662433e-18));
-    T = kr_fma3(zh, T, KR_KS(2.8114572543455206e-15));
-    T = kr_fma3(zh, T, KR_KS(-7.647163731819816e-13));
-    T = kr_fma3(zh, T, KR_KS(1.6059043836821613e-10));
-    T = kr_fma3(zh, T, KR_KS(-2.505210838544172e-08));
-    T = kr_fma3(zh, T, KR_KS(2.7557319223985893e-06));
-    T = kr_fma3(zh, T, KR_KS(-0.0001984126984126984));
+    double T = kr_fma3(zh, 1.9572941063391263e-20, -8.22063524662433e-18);
+    T = kr_fma3(zh, T, 2.8114572543455206e-15);
+    T = kr_fma3(zh, T, -7.647163731819816e-13);
+    T = kr_fma3(zh, T, 1.6059043836821613e-10);
+    T = kr_fma3(zh, T, -2.505210838544172e-08);
+    T = kr_fma3(zh, T, 2.7557319223985893e-06);
+    T = kr_fma3(zh, T, -0.0001984126984126984);
     double s_ph, s_pl;
     {
         const double u = zh * T;
@@ -147,12 +106,12 @@ KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
         s_pl = __builtin_fma(ch, qh, -s_ph) + (ch * ql + cl * qh);
     }
     // cos(r + y) = 1 - z/2 - y sin r + z^2 (C2 + z (C3 + z TC(z)))
-    double TC = kr_fma3(zh, KR_KS(4.110317623312165e-19), KR_KS(-1.5619206968586225e-16));
-    TC = kr_fma3(zh, TC, KR_KS(4.779477332387385e-14));
-    TC = kr_fma3(zh, TC, KR_KS(-1.1470745597729725e-11));
-    TC = kr_fma3(zh, TC, KR_KS(2.08767569878681e-09));
-    TC = kr_fma3(zh, TC, KR_KS(-2.755731922398589e-07));
-    TC = kr_fma3(zh, TC, KR_KS(2.48015873015873e-05));
+    double TC = kr_fma3(zh, 4.110317623312165e-19, -1.5619206968586225e-16);
+    TC = kr_fma3(zh, TC, 4.779477332387385e-14);
+    TC = kr_fma3(zh, TC, -1.1470745597729725e-11);
+    TC = kr_fma3(zh, TC, 2.08767569878681e-09);
+    TC = kr_fma3(zh, TC, -2.755731922398589e-07);
+    TC = kr_fma3(zh, TC, 2.48015873015873e-05);
     {
         const double u = zh * TC;
         const double C3h = -0.001388888888888889, C3l = 5.300543954373577e-20, C2h = 0.041666666666666664, C2l = 2.3129646346357427e-18;
@@ -172,19 +131,19 @@ KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
     }
 }
 
-// CR: the correctly rounded general kernel (default everywhere) or the shorter fdlibm kernels (kept for A/B builds: -DKR_RK45_CR_SINCOS=0 gives the
-// RK45 bodies the short ones, 1e7 rays 0.41 -> 0.38 s; profiles/r02_ab_experiments.txt).  A compile-time property of the caller, so a ray gets the
-// same bits in whichever kernel / wave of ITS integrator it is traced.
-template <bool CR> KR_SC_FN void kr_sincos_t(double x, double& s, double& c)
+// sin and cos of a polar angle, correctly rounded in practice (what every strict-arithmetic caller uses: the integrators' stages, the O(N) passes,
+// the ray sources, the stop tests).  A pure function of x, so a ray gets the same bits in whichever kernel / wave it is traced.
+// (The shorter fdlibm minimax kernels this replaced -- max 0.84 ulp, equal to glibc on 96.5 % of arguments against 99.7-99.99 % -- are in the history
+// of this file; profiles/r02_ab_experiments.txt has their timings.)
+KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
 {
-#if KR_SMALL_ANGLE_SINCOS && KR_COMPACT_SINCOS
     const bool small = __builtin_fabs(x) < KR_SMALL_ANGLE_LIMIT;
 #if defined(__HIP_DEVICE_COMPILE__)
     if (__builtin_amdgcn_ballot_w64(!small) == 0) {      // every active lane: the usual case on a wave of polar-axis rays
         kr_sincos_small_f64(x, s, c);
         return;
     }
-    kr_sincos_general_t<CR>(x, s, c);
+    kr_sincos_general_f64(x, s, c);
     if (__builtin_amdgcn_ballot_w64(small) != 0) {       // mixed wave
         double s1, c1;
         kr_sincos_small_f64(x, s1, c1);
@@ -193,18 +152,12 @@ template <bool CR> KR_SC_FN void kr_sincos_t(double x, double& s, double& c)
     }
 #else
     if (small) kr_sincos_small_f64(x, s, c);
-    else kr_sincos_general_t<CR>(x, s, c);
-#endif
-#else
-    kr_sincos_general_t<CR>(x, s, c);
+    else kr_sincos_general_f64(x, s, c);
 #endif
 }
 
-KR_SC_FN void kr_sincos_f64(double x, double& s, double& c) { kr_sincos_t<(KR_CR_SINCOS != 0)>(x, s, c); }
-
-template <bool CR> KR_SC_FN void kr_sincos_general_t(double x, double& s, double& c)
+KR_SC_FN void kr_sincos_general_f64(double x, double& s, double& c)
 {
-#if KR_COMPACT_SINCOS
     const double ax = __builtin_fabs(x);
     if (__builtin_expect(!(ax < 1024.0), 0)) {
         double ls, lc;                       // (locals: the caller's variables must not have their address handed to an out-of-line call,
@@ -222,26 +175,7 @@ template <bool CR> KR_SC_FN void kr_sincos_general_t(double x, double& s, double
     const double r = __builtin_fma(-t, 6.12323399573676603587e-17, r0);     // P2 = pi/2 - P1
     const double y = __builtin_fma(-t, 6.12323399573676603587e-17, r0 - r); // what rounding r dropped
     double sr, cr;
-    if constexpr (CR) {
     kr_sincos_cr_core_f64(r, y - t * -1.4973849048591698e-33, sr, cr);                            // (third piece of pi/2)
-    } else {
-    const double z = r * r;
-    // sin(r + y)
-    const double v = z * r;
-    const double ps = kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, KR_KS(1.58969099521155010221e-10), KR_KS(-2.50507602534068634195e-08)),
-                                                          KR_KS(2.75573137070700676789e-06)), KR_KS(-1.98412698298579493134e-04)), KR_KS(8.33333333332248946124e-03));
-    sr = r - ((z * (0.5 * y - v * ps) - y) - v * -1.66666666666666324348e-01);
-    // cos(r + y)
-    const double pc = z * kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, kr_fma3(z, KR_KS(-1.13596475577881948265e-11), KR_KS(2.08757232129817482790e-09)),
-                                                                      KR_KS(-2.75573143513906633035e-07)), KR_KS(2.48015872894767294178e-05)), KR_KS(-1.38888888888741095749e-03)), KR_KS(4.16666666666666019037e-02));
-    const double ar = __builtin_fabs(r);
-    // qx ~ |r|/4 with a short mantissa, so that 1 - qx and z/2 - qx are exact (0 below 0.3, capped at 0.28125)
-    const unsigned long long qbits = (__builtin_bit_cast(unsigned long long, ar) - 0x0020000000000000ull) & 0xFFFFFFFF00000000ull;
-    double qx = __builtin_bit_cast(double, qbits);
-    qx = (ar > 0.78125) ? 0.28125 : qx;
-    qx = (ar < 0.3) ? 0.0 : qx;
-    cr = (1.0 - qx) - ((0.5 * z - qx) - (z * pc - r * y));
-    }
     // quadrant: sin -> {s, c, -s, -c}[n & 3], cos -> {c, -s, -c, s}[n & 3]
     const bool odd = (n & 1) != 0;
     const double ss = odd ? cr : sr;
@@ -250,9 +184,6 @@ template <bool CR> KR_SC_FN void kr_sincos_general_t(double x, double& s, double
     const unsigned long long sgn_c = ((unsigned long long) (unsigned) ((n + 1) & 2)) << 62;
     s = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, ss) ^ sgn_s);
     c = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, cc) ^ sgn_c);
-#else
-    sincos(x, &s, &c);
-#endif
 }
 
 // The same pair for the fast arithmetic path (kr_device.hpp: momentum_fast / k1_with_flips_fast), which tolerates a few
@@ -277,17 +208,17 @@ KR_SC_FN void kr_sincos_fast_core_f64(double x, double& s, double& c)
     double r = __builtin_fma(-t, 1.57079632679489655800e+00, x);
     r = __builtin_fma(-t, 6.12323399573676603587e-17, r);
     const double z = r * r;
-    double ps = kr_fma3(z, KR_K(1.58969099521155010221e-10), KR_K(-2.50507602534068634195e-08));
-    ps = kr_fma3(z, ps, KR_K(2.75573137070700676789e-06));
-    ps = kr_fma3(z, ps, KR_K(-1.98412698298579493134e-04));
-    ps = kr_fma3(z, ps, KR_K(8.33333333332248946124e-03));
-    ps = kr_fma3(z, ps, KR_K(-1.66666666666666324348e-01));
+    double ps = kr_fma3(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = kr_fma3(z, ps, 2.75573137070700676789e-06);
+    ps = kr_fma3(z, ps, -1.98412698298579493134e-04);
+    ps = kr_fma3(z, ps, 8.33333333332248946124e-03);
+    ps = kr_fma3(z, ps, -1.66666666666666324348e-01);
     const double sr = __builtin_fma(r * z, ps, r);
-    double pc = kr_fma3(z, KR_K(-1.13596475577881948265e-11), KR_K(2.08757232129817482790e-09));
-    pc = kr_fma3(z, pc, KR_K(-2.75573143513906633035e-07));
-    pc = kr_fma3(z, pc, KR_K(2.48015872894767294178e-05));
-    pc = kr_fma3(z, pc, KR_K(-1.38888888888741095749e-03));
-    pc = kr_fma3(z, pc, KR_K(4.16666666666666019037e-02));
+    double pc = kr_fma3(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = kr_fma3(z, pc, -2.75573143513906633035e-07);
+    pc = kr_fma3(z, pc, 2.48015872894767294178e-05);
+    pc = kr_fma3(z, pc, -1.38888888888741095749e-03);
+    pc = kr_fma3(z, pc, 4.16666666666666019037e-02);
     pc = __builtin_fma(z, pc, -0.5);
     const double cr = __builtin_fma(z, pc, 1.0);
     const bool odd = (n & 1) != 0;

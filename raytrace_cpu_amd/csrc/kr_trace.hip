@@ -44,22 +44,12 @@ namespace kr {
 namespace {
 
 constexpr int kBlock = 256;          // classification kernel
-#ifndef KR_TRACE_BLOCK
-#define KR_TRACE_BLOCK 64            // trace kernel: one wave per workgroup -- a wave gives its registers back the moment IT has finished, not when the
-                                     // slowest of four has: main launch 93.1 -> 87.2 ms at 1e7 rays (256: four independent waves per workgroup)
-#endif
-constexpr int kTraceBlock = KR_TRACE_BLOCK;
-constexpr int kWavesPerBlock = kTraceBlock / 64;
-// HOG instances (the strict side launch): one wave per workgroup too, and the first claims are static (wave g takes list slots 64 g ..), so the
-// listed rays go to the lowest-numbered workgroups -- which the dispatcher spreads over as many compute units -- and every other workgroup leaves
-// at once.  -DKR_HOG_BLOCK=256 puts four such waves in a workgroup, which then owns its compute unit (no wave of the main launch beside the
-// critical rays' waves): MEASURED WORSE -- four lone waves on one CU slow one another down more than nine waves of the main launch do (RK45 1e7
-// rays 385 -> 411 ms, Euler 36.5 -> 38.1, RK4 headline 72.2 -> 71.7: profiles/r03_ab_experiments.txt).
-#ifndef KR_HOG_BLOCK
-#define KR_HOG_BLOCK 64
-#endif
-constexpr int kHogBlock = KR_HOG_BLOCK;
-constexpr int block_of(bool hog) { return hog ? kHogBlock : kTraceBlock; }
+// Trace kernels: ONE wave per workgroup -- a wave gives its registers back the moment IT has finished, not when the slowest of four has
+// (main launch 93.1 -> 87.2 ms at 1e7 rays against 256-thread workgroups).  The HOG instances (the strict side launch) too: their first claims
+// are static (wave g takes list slots 64 g ..), so the listed rays go to the lowest-numbered workgroups -- which the dispatcher spreads over as
+// many compute units -- and every other workgroup leaves at once.  (Four HOG waves per workgroup, i.e. a workgroup that owns its compute unit,
+// measured worse: four lone waves on one CU slow one another down more than nine waves of the main launch do; profiles/r03_ab_experiments.txt.)
+constexpr int kTraceBlock = 64;
 // A wave goes back to the queue when at least this many of its lanes are free (or none holds a ray).  The refill / finish / store code runs with
 // only the free lanes active, ~500 vector instructions per visit -- as much as an RK4 step: visiting for every single finished lane cost the image
 // plane (1.25 lanes per visit) 11 % and the Euler launches 26 %; waiting for 4 leaves ~1.5 lanes of 64 idle on average.
@@ -68,22 +58,14 @@ constexpr int block_of(bool hog) { return hog ? kHogBlock : kTraceBlock; }
 #ifndef KR_REFILL_MIN
 #define KR_REFILL_MIN 4
 #endif
-#ifndef KR_LONG_RAY_PRIO
-#define KR_LONG_RAY_PRIO 1
-#endif
-#ifndef KR_GRADED_PRIO
-#define KR_GRADED_PRIO 1
-#endif
-#ifndef KR_LONG_RAY_STEPS
-#define KR_LONG_RAY_STEPS 2048
-#endif
+constexpr int kLongRaySteps = 2048;  // a wave whose oldest ray is older than 1 x / 3 x / 8 x this raises its issue priority to 1 / 2 / 3 (trace_body)
 #ifndef KR_OCC_STATS
 #define KR_OCC_STATS 0               // 1: lane-occupancy bookkeeping of the step loop (diagnostic builds: scripts/gpu_occ_stats.sh), printed by trace_wait
 #endif
 constexpr int kCounters = KR_OCC_STATS ? 13 : 8;         // [0] queue head, [1] rays traced, [2] steps, [3] rk45 attempts, [4] rk45 rejects, [5] rk45 stationary steps, [6] rk45 extrapolated steps,
                                                          // [7] steps of the launch's longest ray (atomicMax); KR_OCC_STATS builds: [8..12] occupancy sums
 constexpr int kCounterBlocks = 4;    // main launch, strict side launch, strict overflow launch, split bookkeeping ([1] = number of ill-conditioned rays)
-constexpr int kListCap = 32768;      // index-list entries of the strict side launch (= 128 workgroups x 256 lanes, half of the chip)
+constexpr int kListCap = 32768;      // index-list entries of the strict side launch
 
 template <typename T> struct RayOf;
 template <> struct RayOf<double> { using type = kr_ray_f64; };
@@ -133,65 +115,6 @@ KR_DEV void store_ray(kr_ray_f32* p, const Lane<float>& s, int32_t out_steps)
     p->rdot_flips = s.rdot_flips; p->equatorial_crossings = s.eq_cross;
 }
 
-// ---- where a trace kernel's rays come from and where they go ---------------------------------------------------------
-// RecordIO: the reference's own records in HBM (every entry point of the class API).
-template <typename T> struct RecordIO {
-    typename RayOf<T>::type* __restrict__ rays;
-    KR_DEV long long load(long long i, Lane<T>& s) const { load_ray(&rays[i], s); return i; }      // (returns what store() is to be handed)
-    KR_DEV void store(long long i, const Lane<T>& s, int32_t out_steps) const { store_ray(&rays[i], s, out_steps); }
-};
-
-// ---- the emissivity pipeline inside the trace kernel (kr_emissivity_pipeline_dev_f64): NO ray record exists in memory ----
-// Source rays are built in the kernel (pointsource.cpp:30-64 + calculate_constants, raytracer.cpp:625-676), finished rays are redshifted
-// (raytracer.cpp:342-417, :420-553) and added to the workgroup's copy of the radial histogram in LDS (emissivity.cpp:96-126), flushed with one
-// global atomic per non-empty word when the wave leaves.  The per-ray functions are the ones the streaming kernels of kr_post.hip use
-// (kr_post_device.hpp): same bits per ray; the sums differ from theirs only in the order of addition.
-// Both ends are a few thousand instructions per ray, and a wave visits the work queue when FOUR of its lanes are free: run by the lanes that
-// need them they execute at 6-12 % lane occupancy and cost more than a third of the stepping itself (first version: main launch 65 -> 83 ms).
-// So both ends run on FULL waves and meet the step loop through two small rings in LDS (one wave per workgroup: no barriers):
-//   in-ring   a visit that finds the ring short claims 64 queue slots and ALL 64 lanes build one source ray each; what a ray IS -- k, h, Q and
-//             its two initial direction signs; every ray of a PointSource starts at the same event -- is pushed (valid rays only); the free
-//             lanes pop;
-//   out-ring  lanes whose ray has ended push r, theta, t, k, h, Q, the signs and the step count; whenever 64 are waiting (and when the wave
-//             leaves) all lanes take one each through redshift_start's `emit`, redshift and the histogram.
-// Layout of a workgroup's (= a wave's) dynamic LDS, in doubles from pipe_lds: [histogram: hist_words][in_k, in_h, in_Q: 64 each][out_r, out_theta,
-// out_t, out_k, out_h, out_Q: 128 each] then ints [in_meta: 64][out_steps: 128][out_meta: 128].  Addressed as pipe_lds[offset + i] throughout, so
-// that every access is a ds_read / ds_write at a constant offset from ONE base register (a struct of pointers cost the step loop 24 registers and
-// turned the accesses into flat ones: main launch 265 ms).
-//   in_meta: bit 0 rdot_sign < 0, bit 1 thetadot_sign < 0;   out_meta: bits 0-1 the initial signs, bits 2-3 the final ones
-extern __shared__ double pipe_lds[];
-struct PipeRings {
-    static constexpr int kIn = 64, kOut = 128;
-    static constexpr int kInK = 0, kInH = kIn, kInQ = 2 * kIn, kOutR = 3 * kIn, kOutTheta = kOutR + kOut, kOutT = kOutR + 2 * kOut, kOutK = kOutR + 3 * kOut,
-                         kOutH = kOutR + 4 * kOut, kOutQ = kOutR + 5 * kOut, kDoubles = kOutR + 6 * kOut;
-    static constexpr int kInMeta = 0, kOutSteps = kIn, kOutMeta = kIn + kOut, kInts = kIn + 2 * kOut;
-    static size_t bytes(int hist_words) { return (size_t) (hist_words + kDoubles) * 8 + (size_t) kInts * 4; }
-};
-
-// The two ends are OUT-OF-LINE functions, called from a visit that keeps nothing of the step loop's state in registers (it is parked in private
-// memory, trace_body_pipe): their register appetite -- thousands of instructions each -- is then their own.  Inlined, they shared one allocation
-// with the step loop and left it with ~40 spill accesses per step (SQ_INSTS_VMEM 3.4e9 per launch against 3.4e7: main launch 65 -> 240-265 ms).
-struct PipeSourceRay { double k, h, Q; int meta, steps; };
-__device__ __attribute__((noinline)) PipeSourceRay pipe_source(const EmisPipeArgs* a, long long ix)
-{
-    const kr_ray_f64 ray = pointsource_ray(a->src, a->n_grid, a->n_beta, ix);
-    return PipeSourceRay{ray.k, ray.h, ray.Q, (ray.rdot_sign < 0 ? 1 : 0) | (ray.thetadot_sign < 0 ? 2 : 0), ray.steps};
-}
-
-// one finished ray through redshift_start's emit, redshift() and the histogram
-__device__ __attribute__((noinline)) void pipe_sink(const EmisPipeArgs& a, double* hist, double a_start, double V_start, double log_dr, double r, double theta, double t, double k, double h,
-                      double Q, int meta, int out_steps)
-{
-    kr_ray_f64 v;
-    v.r = a.src.pos[1]; v.theta = a.src.pos[2];              // where every ray of the source starts
-    v.k = k; v.h = h; v.Q = Q;
-    v.rdot_sign = (meta & 1) ? -1 : 1; v.thetadot_sign = (meta & 2) ? -1 : 1;
-    v.emit = emit_value(v, a.src.spin, a_start, V_start, a.reverse_start);
-    v.r = r; v.theta = theta; v.rdot_sign = (meta & 4) ? -1 : 1; v.thetadot_sign = (meta & 8) ? -1 : 1;
-    const double g = redshift_value(v, a.spin, a.V, a.reverse, a.projradius, a.motion);
-    emissivity_accumulate(hist, a.bins, log_dr, out_steps, r, theta, g, t);
-}
-
 KR_DEV unsigned long long wave_max(unsigned long long v)
 {
 #pragma unroll
@@ -217,20 +140,10 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 // rays with mask[i] == mask_want are traced (the others belong to another launch of the split).  HOG: the kernel claims the whole register
 // file (512 VGPR+AGPR per lane), so each of its waves owns its SIMD and no other kernel's wave can be co-resident on
 // the CUs it occupies -- used for the few ill-conditioned / long rays that define the critical path.
-#ifndef KR_HOG_ATTR
-// HOG: the scheduler may trade registers for ILP.  Otherwise: RK4 must keep 3 waves per SIMD (<= 168 VGPRs), RK45 2.
-#ifndef KR_HOG_MAX_WAVES
-#define KR_HOG_MAX_WAVES 8   // measured: (1,1) makes the side launch 2 % slower
-#endif
-#ifndef KR_RK4_MIN_WAVES
-#define KR_RK4_MIN_WAVES 3
-#endif
-#ifndef KR_EULER_MIN_WAVES
-#define KR_EULER_MIN_WAVES 4   // the Euler step is short and branchy (173 vector + ~100 scalar instructions, ~25 branches): at 3 waves per SIMD the vector
-                               // unit is 78 % busy; 1e7 rays 38.5 / 31.4 / 28.3 ms at 2 / 3 / 4 resident waves (profiles/r03_ab_experiments.txt)
-#endif
-#define KR_HOG_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? KR_RK4_MIN_WAVES : METHOD == KR_RK45 ? 2 : KR_EULER_MIN_WAVES, HOG ? KR_HOG_MAX_WAVES : 8)))
-#endif
+// Resident waves per SIMD the register allocation must allow: HOG 1 (the scheduler may trade registers for ILP; capping it at (1, 1) measured 2 %
+// slower), RK4 3 (<= 168 VGPRs), RK45 2, Euler 4 (its step is short and branchy: at 3 waves per SIMD the vector unit is 78 % busy; 1e7 rays
+// 38.5 / 31.4 / 28.3 ms at 2 / 3 / 4 resident waves, profiles/r03_ab_experiments.txt).
+#define KR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? 3 : METHOD == KR_RK45 ? 2 : 4, 8)))
 // everything one trace launch works on; a batch of traces hands the kernel an array of these (trace_multi_kernel)
 template <typename T> struct TraceDesc {
     typename RayOf<T>::type* rays;
@@ -243,8 +156,8 @@ template <typename T> struct TraceDesc {
     int n_mode, mask_want;
 };
 
-template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN, class IO>
-KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsigned long long* __restrict__ counters,
+template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
+KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, const TraceConsts<T>& c, unsigned long long* __restrict__ counters,
                        const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want,
                        int& has_prio, long long first_slot = -1, unsigned long long head_offset = 0)
 {
@@ -265,9 +178,7 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
     unsigned long long my_steps = 0, my_traced = 0;
     int32_t my_longest = 0;     // most steps any of this lane's rays took in this call
     uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
-#if KR_LONG_RAY_PRIO
     unsigned prio_tick = 0;
-#endif
 
 #if KR_OCC_STATS
     unsigned long long occ_iters = 0, occ_tail_iters = 0, occ_tail_steps = 0, occ_refills = 0, occ_refill_lanes = 0;
@@ -278,7 +189,7 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
         const bool any_have = (need != ~0ull);
 
         // A wave visits the queue when enough of its lanes are free, and once more when it leaves: rays that have ended since the last visit are
-        // written out there -- the ONE place in the kernel where a ray is stored (the pipeline instances' store path is a few thousand instructions).
+        // written out there -- the ONE place in the kernel where a ray is stored.
         const bool visit = !exhausted && n_need > 0 && (n_need >= REFILL_MIN || !any_have);
         const bool leaving = !visit && !any_have;          // nothing held and nothing left to take
         if (visit || leaving) {
@@ -287,7 +198,7 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
                 // lane's ~40 instructions)
                 my_steps += (unsigned long long) s.steps;
                 my_longest = s.steps > my_longest ? s.steps : my_longest;
-                io.store(idx, s, finish_status<T, USE_DEST>(s, c));
+                store_ray(&rays[idx], s, finish_status<T, USE_DEST>(s, c));
                 pend = false;
             }
             if (leaving) break;
@@ -310,10 +221,10 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
                 const long long slot = (long long) base + __popcll(need & (lane_bit - 1));
                 if (slot < n && !(mask && mask[slot] != (unsigned char) mask_want)) {
                     const long long mine = list ? (long long) list[slot] : slot;
-                    const long long handle = io.load(mine, s);
+                    load_ray(&rays[mine], s);
                     // skip rule of run_raytrace (raytracer.cpp:116-117)
                     if (s.steps0 >= 0 && s.steps0 < c.steplim) {
-                        idx = handle;
+                        idx = mine;
                         have = true;
                         ++my_traced;
                         s.steps = 0;
@@ -324,7 +235,6 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
                         s.creep_run = 0;
                         s.creep_mode = false;
                         s.fsal_valid = false;
-                        s.carry_ok = false;
                         if (METHOD == KR_RK45) rk45_seed(s, c);
                         if (!loop_cond<T, USE_DEST>(s, c)) {
                             // zero-iteration call: only the epilogue runs (at the next visit)
@@ -337,7 +247,6 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
             continue;   // re-evaluate the ballots (skipped / zero-iteration rays leave lanes free)
         }
 
-#if KR_LONG_RAY_PRIO
         if (!HOG && (++prio_tick & 15) == 0)   // (a wave that owns its SIMD has nobody to take priority over; the thresholds are thousands of steps)
         // The launch cannot end before its longest ray does, and a ray advances one step per iteration of ITS wave:
         // a wave that carries a long ray (orbiting / polar-axis rays: 2e4..1e7 steps against a median of ~450) is
@@ -347,11 +256,7 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
             // graded: the longer the wave's oldest ray, the higher its priority (0..3), so the rays that define the
             // critical path do not have to share their priority level with the many merely "longish" ones
             const int32_t st = have ? s.steps : 0;
-#if KR_GRADED_PRIO
-            const int want_prio = __any(st > 8 * KR_LONG_RAY_STEPS) ? 3 : __any(st > 3 * KR_LONG_RAY_STEPS) ? 2 : __any(st > KR_LONG_RAY_STEPS) ? 1 : 0;
-#else
-            const int want_prio = __any(st > KR_LONG_RAY_STEPS) ? 3 : 0;
-#endif
+            const int want_prio = __any(st > 8 * kLongRaySteps) ? 3 : __any(st > 3 * kLongRaySteps) ? 2 : __any(st > kLongRaySteps) ? 1 : 0;
             if (want_prio != has_prio) {
                 has_prio = want_prio;
                 switch (want_prio) {
@@ -362,7 +267,6 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
                 }
             }
         }
-#endif
 
         int replay_batch = 1;
         if constexpr (METHOD == KR_RK45 && sizeof(T) == 8) {
@@ -413,329 +317,18 @@ KR_DEV void trace_body(const IO& io, long long n, const TraceConsts<T>& c, unsig
 }
 
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(block_of(HOG), block_of(HOG)))) KR_HOG_ATTR
+__global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_WAVES_ATTR
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
              const int* __restrict__ list, const unsigned long long* __restrict__ n_ptr, int n_mode, const unsigned char* __restrict__ mask, int mask_want)
 {
     if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
     int has_prio = 0;
     if constexpr (HOG) {
-        constexpr int kWaves = kHogBlock / 64;
-        const long long g = (long long) blockIdx.x * kWaves + (threadIdx.x >> 6);
-        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(RecordIO<T>{rays}, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio, g * 64,
-                                                               (unsigned long long) gridDim.x * kWaves * 64);
+        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(rays, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio, (long long) blockIdx.x * 64,
+                                                               (unsigned long long) gridDim.x * 64);
     } else {
-        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(RecordIO<T>{rays}, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio);
+        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(rays, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio);
     }
-}
-
-// The persistent loop of trace_body with the emissivity pipeline's two rings at its queue visits (double precision, theta-limit overload).
-// The WHOLE visit is one out-of-line function working on memory: the lane's state parked in private memory (PipeParked) and the wave's pipeline
-// state (PipeCtx: the two ring fills, the queue, copies of the arguments).  The step loop around it then carries strictly less than the record
-// kernel's does -- the visit's scalars had pushed the loop's hoisted constants out of the scalar file into a spill register and from there the
-// polynomial constants into scratch: ~11 scratch accesses and ~80 extra vector instructions PER STEP (main launch 102 ms against 64).
-struct PipeParked { Lane<double> s; unsigned long long my_steps, my_traced; int meta0, my_longest; bool have, pend; };
-struct PipeCtx {
-    EmisPipeArgs a;
-    TraceConsts<double> c;
-    double* hist;                  // the wave's histogram (LDS) or the global one
-    double* rings;                 // the rings' doubles; their ints follow at rings + PipeRings::kDoubles
-    double a_start, V_start, log_dr;
-    long long n, first_slot;
-    unsigned long long head_offset;
-    unsigned long long* counters;
-    const int* list;
-    const unsigned char* mask;
-    int mask_want, in_count, out_count;
-    bool exhausted;
-};
-KR_DEV double& ring_d(const PipeCtx* x, int field, int i) { return x->rings[field + i]; }
-KR_DEV int& ring_i(const PipeCtx* x, int field, int i) { return reinterpret_cast<int*>(x->rings + PipeRings::kDoubles)[field + i]; }
-
-// returns "dry": the queue is exhausted and the in-ring empty (no further visit can hand out a ray)
-// (one instance per kernel instance -- FAST and HOG change nothing in it -- so that each inherits ITS kernel's register budget: shared between a
-// 512-register HOG kernel and a 168-register main kernel it took 194 and pushed the main kernel to 2 waves per SIMD)
-template <int METHOD, bool FAST, bool HOG>
-__device__ __attribute__((noinline)) bool pipe_visit(PipeParked* pk, PipeCtx* x, bool leaving)
-{
-    using T = double;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lanes_below = (1ull << lane) - 1;
-    Lane<T>& s = pk->s;
-    const unsigned long long need = __ballot(!pk->have);
-    const int n_need = __popcll(need);
-    int in_count = x->in_count, out_count = x->out_count;
-    // (1) rays that have ended since the last visit -> out-ring
-    const unsigned long long pm = __ballot(pk->pend);
-    if (pm != 0) {
-        if (pk->pend) {
-            const int e = out_count + __popcll(pm & lanes_below);
-            pk->my_steps += (unsigned long long) s.steps;
-            pk->my_longest = s.steps > pk->my_longest ? s.steps : pk->my_longest;
-            ring_i(x, PipeRings::kOutSteps, e) = finish_status<T, false>(s, x->c);
-            ring_d(x, PipeRings::kOutR, e) = s.r; ring_d(x, PipeRings::kOutTheta, e) = s.theta; ring_d(x, PipeRings::kOutT, e) = s.t;
-            ring_d(x, PipeRings::kOutK, e) = s.k; ring_d(x, PipeRings::kOutH, e) = s.h; ring_d(x, PipeRings::kOutQ, e) = s.Q;
-            ring_i(x, PipeRings::kOutMeta, e) = pk->meta0 | (s.rdot_sign < 0 ? 4 : 0) | (s.thetadot_sign < 0 ? 8 : 0);
-            pk->pend = false;
-        }
-        out_count += __popcll(pm);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (other lanes read these entries: LDS writes before the reads below)
-        __builtin_amdgcn_wave_barrier();
-    }
-    // (2) the sink, on full waves: 64 waiting rays at a time (whatever is left when the wave leaves)
-    while (out_count >= 64 || (leaving && out_count > 0)) {
-        const int m = out_count < 64 ? out_count : 64;
-        const int e = out_count - m + lane;
-        if (lane < m)
-            pipe_sink(x->a, x->hist, x->a_start, x->V_start, x->log_dr, ring_d(x, PipeRings::kOutR, e), ring_d(x, PipeRings::kOutTheta, e), ring_d(x, PipeRings::kOutT, e),
-                      ring_d(x, PipeRings::kOutK, e), ring_d(x, PipeRings::kOutH, e), ring_d(x, PipeRings::kOutQ, e), ring_i(x, PipeRings::kOutMeta, e),
-                      ring_i(x, PipeRings::kOutSteps, e));
-        out_count -= m;
-    }
-    // (3) free lanes take rays from the in-ring; when it runs dry, ALL lanes build the next 64 queue slots' rays into it
-    bool exhausted = x->exhausted;
-    int wanted = leaving ? 0 : n_need;
-    while (wanted > 0) {
-        const int take = wanted < in_count ? wanted : in_count;
-        if (take > 0) {
-            const int rank = __popcll(need & lanes_below) - (n_need - wanted);       // this free lane's turn among those still waiting
-            if (!pk->have && rank >= 0 && rank < take) {
-                const int e = in_count - 1 - rank;
-                s.t = x->a.src.pos[0]; s.r = x->a.src.pos[1]; s.theta = x->a.src.pos[2]; s.phi = x->a.src.pos[3];
-                s.pt = 0; s.pr = 0; s.ptheta = 0; s.pphi = 0;
-                s.k = ring_d(x, PipeRings::kInK, e); s.h = ring_d(x, PipeRings::kInH, e); s.Q = ring_d(x, PipeRings::kInQ, e);
-                const int meta0 = ring_i(x, PipeRings::kInMeta, e);
-                pk->meta0 = meta0;
-                s.rdot_sign = (meta0 & 1) ? -1 : 1; s.thetadot_sign = (meta0 & 2) ? -1 : 1;
-                s.steps0 = 0; s.status = 0; s.rdot_flips = 0; s.eq_cross = 0;
-                pk->have = true;
-                ++pk->my_traced;
-                s.steps = 0;
-                s.r_was_positive = false;
-                s.theta_was_positive = true;
-                s.in_retry = false;
-                s.creep_m = 0;
-                s.creep_run = 0;
-                s.creep_mode = false;
-                s.fsal_valid = false;
-                s.carry_ok = false;
-                if (METHOD == KR_RK45) rk45_seed(s, x->c);
-                if (!loop_cond<T, false>(s, x->c)) { pk->have = false; pk->pend = true; }      // zero-iteration call: only the epilogue runs (at the next visit)
-            }
-            in_count -= take;
-            wanted -= take;
-        }
-        if (wanted == 0 || exhausted) break;
-        // the ring is empty here: claim 64 slots, one source ray per lane
-        unsigned long long base = 0;
-        if (x->first_slot >= 0) {
-            base = (unsigned long long) x->first_slot;
-            x->first_slot = -1;
-        } else {
-            if (lane == 0) base = atomicAdd(&x->counters[0], 64ull);
-            base = __shfl(base, 0, 64) + x->head_offset;
-        }
-        if (base + 64ull >= (unsigned long long) x->n) exhausted = true;
-        const long long slot = (long long) base + lane;
-        bool valid = slot < x->n && !(x->mask && x->mask[slot] != (unsigned char) x->mask_want);
-        PipeSourceRay ray{0, 0, 0, 0, -1};
-        if (valid) {
-            const long long mine = x->list ? (long long) x->list[slot] : slot;
-            ray = pipe_source(&x->a, x->a.first + mine * x->a.stride);
-        }
-        valid = valid && ray.steps >= 0 && ray.steps < x->c.steplim;                  // skip rule of run_raytrace (raytracer.cpp:116-117)
-        const unsigned long long vm = __ballot(valid);
-        if (valid) {
-            const int e = in_count + __popcll(vm & lanes_below);
-            ring_d(x, PipeRings::kInK, e) = ray.k; ring_d(x, PipeRings::kInH, e) = ray.h; ring_d(x, PipeRings::kInQ, e) = ray.Q;
-            ring_i(x, PipeRings::kInMeta, e) = ray.meta;
-        }
-        in_count += __popcll(vm);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    }
-    x->in_count = in_count; x->out_count = out_count; x->exhausted = exhausted;
-    return exhausted && in_count == 0;
-}
-
-template <int METHOD, bool FAST, bool HOG, int REFILL_MIN>
-KR_DEV void trace_body_pipe(PipeCtx* x, const TraceConsts<double>& c, unsigned long long* __restrict__ counters, int& has_prio)
-{
-    using T = double;
-    const int lane = threadIdx.x & 63;
-    Lane<T> s;
-    int meta0 = 0;              // the ray's initial direction signs (pipe_sink needs them for `emit`)
-    bool have = false, pend = false;
-    bool dry = false;           // wave-uniform: queue exhausted and in-ring empty
-    unsigned long long my_steps = 0, my_traced = 0;
-    int32_t my_longest = 0;
-    uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
-    PipeParked pk;
-    pk.my_longest = 0;          // (only the visit touches it)
-#if KR_OCC_STATS
-    unsigned long long occ_iters = 0, occ_tail_iters = 0, occ_tail_steps = 0, occ_refills = 0, occ_refill_lanes = 0;
-#endif
-#if KR_LONG_RAY_PRIO
-    unsigned prio_tick = 0;
-#endif
-    for (;;) {
-        const unsigned long long need = __ballot(!have);
-        const int n_need = __popcll(need);
-        const bool any_have = (need != ~0ull);
-        const bool visit = n_need > 0 && (n_need >= REFILL_MIN || !any_have) && !dry;
-        const bool leaving = !visit && !any_have;
-        if (visit || leaving) {
-#if KR_OCC_STATS
-            ++occ_refills; occ_refill_lanes += n_need;
-#endif
-            // ~45 stores and loads per visit, once per ~60 wave steps
-            pk.s = s; pk.meta0 = meta0; pk.have = have; pk.pend = pend; pk.my_steps = my_steps; pk.my_traced = my_traced;
-            dry = __any(pipe_visit<METHOD, FAST, HOG>(&pk, x, leaving));
-            s = pk.s; meta0 = pk.meta0; have = pk.have; pend = pk.pend; my_steps = pk.my_steps; my_traced = pk.my_traced;
-            if (leaving) { my_longest = pk.my_longest; break; }
-            continue;
-        }
-
-#if KR_LONG_RAY_PRIO
-        if (!HOG && (++prio_tick & 15) == 0) {      // (see trace_body)
-            const int32_t st = have ? s.steps : 0;
-            const int want_prio = __any(st > 8 * KR_LONG_RAY_STEPS) ? 3 : __any(st > 3 * KR_LONG_RAY_STEPS) ? 2 : __any(st > KR_LONG_RAY_STEPS) ? 1 : 0;
-            if (want_prio != has_prio) {
-                has_prio = want_prio;
-                switch (want_prio) {
-                    case 3: __builtin_amdgcn_s_setprio(3); break;
-                    case 2: __builtin_amdgcn_s_setprio(2); break;
-                    case 1: __builtin_amdgcn_s_setprio(1); break;
-                    default: __builtin_amdgcn_s_setprio(0); break;
-                }
-            }
-        }
-#endif
-        int replay_batch = 1;
-        if constexpr (METHOD == KR_RK45) {
-            if (!__any(have && !s.creep_mode)) replay_batch = 16;
-        }
-#if KR_OCC_STATS
-        ++occ_iters;
-        if (dry) { ++occ_tail_iters; occ_tail_steps += have ? 1 : 0; }
-#endif
-        if (have) {
-            bool fin;
-            if (METHOD == KR_EULER) fin = step_fixed<T, false, false, FAST>(s, c);
-            else if (METHOD == KR_RK4) fin = step_fixed<T, true, false, FAST>(s, c);
-            else fin = step_rk45<T, false, FAST>(s, c, my_attempts, my_rejects, my_stationary, my_creep, replay_batch);
-            if (fin) { have = false; pend = true; }
-        }
-    }
-
-    const unsigned long long w_traced = wave_sum<T>(my_traced);
-    const unsigned long long w_steps = wave_sum<T>(my_steps);
-    const unsigned long long w_att = wave_sum<T>((unsigned long long) my_attempts);
-    const unsigned long long w_rej = wave_sum<T>((unsigned long long) my_rejects);
-    const unsigned long long w_sta = wave_sum<T>((unsigned long long) my_stationary);
-    const unsigned long long w_creep = wave_sum<T>((unsigned long long) my_creep);
-    const unsigned long long w_longest = wave_max((unsigned long long) my_longest);
-#if KR_OCC_STATS
-    {
-        const unsigned long long w_tail_steps = wave_sum<T>(occ_tail_steps);
-        if (lane == 0) {
-            atomicAdd(&counters[8], occ_iters); atomicAdd(&counters[9], occ_tail_iters); atomicAdd(&counters[10], w_tail_steps);
-            atomicAdd(&counters[11], occ_refills); atomicAdd(&counters[12], occ_refill_lanes);
-        }
-    }
-#endif
-    if (lane == 0) {
-        if (w_longest) atomicMax(&counters[7], w_longest);
-        if (w_sta) atomicAdd(&counters[5], w_sta);
-        if (w_creep) atomicAdd(&counters[6], w_creep);
-        if (w_traced) atomicAdd(&counters[1], w_traced);
-        if (w_steps) atomicAdd(&counters[2], w_steps);
-        if (w_att) atomicAdd(&counters[3], w_att);
-        if (w_rej) atomicAdd(&counters[4], w_rej);
-    }
-}
-
-// The wave's pipeline state is set up, and its histogram flushed, out of line as well, and pipe_begin reads the kernel's arguments through the
-// kernarg segment pointer (handed to it) rather than through references: nothing of them but the trace constants stays in scalar registers across the step loop,
-// and no argument's address is taken (a kernel argument whose address escapes is copied to private memory and read from THERE ever after: the
-// trace constants would move from scalar registers into 60 vector registers).
-struct PipeKernArgs {
-    EmisPipeArgs args;
-    long long n;
-    TraceConsts<double> c;
-    unsigned long long* counters;
-    const int* list;
-    const unsigned long long* n_ptr;
-    const unsigned char* mask;
-    int n_mode, mask_want;
-};
-
-template <int METHOD, bool FAST, bool HOG>
-__device__ __attribute__((noinline)) void pipe_begin(PipeCtx* x, const PipeKernArgs* ka, double* lds, long long first_slot, unsigned long long head_offset)
-{
-    const EmisPipeArgs& args = ka->args;
-    const int words = 5 * args.bins.nr + 1;
-    const int lds_words = args.use_lds ? words : 0;           // the rings follow the histogram
-    for (int w = threadIdx.x; w < lds_words; w += 64) lds[w] = 0;
-    x->a = args;
-    x->c = ka->c;
-    x->hist = args.use_lds ? lds : args.hist;
-    x->rings = lds + lds_words;
-    x->a_start = args.reverse_start ? -1 * args.src.spin : args.src.spin;
-    x->V_start = args.V_start;
-    if (x->V_start == -1) {       // the orbital velocity at source ray 0, kept for every ray (raytracer.cpp:389-393)
-        const kr_ray_f64 r0 = pointsource_ray(args.src, args.n_grid, args.n_beta, 0);
-        x->V_start = keplerian_V<double>(x->a_start, r0.r, r0.theta, args.projradius_start != 0);
-    }
-    x->log_dr = kr_log(args.bins.dr);
-    long long n = ka->n;
-    if (ka->n_ptr) {
-        const long long m = (long long) *ka->n_ptr;
-        n = (ka->n_mode == 1) ? (m < n ? m : n) : (m > (long long) kListCap ? n : 0);
-    }
-    x->n = n;
-    x->first_slot = first_slot;
-    x->head_offset = head_offset;
-    x->counters = ka->counters; x->list = ka->list; x->mask = ka->mask; x->mask_want = ka->mask_want;
-    x->in_count = 0; x->out_count = 0; x->exhausted = false;
-}
-
-template <int METHOD, bool FAST, bool HOG>
-__device__ __attribute__((noinline)) void pipe_end(PipeCtx* x)
-{
-    if (!x->a.use_lds) return;
-    const int words = 5 * x->a.bins.nr + 1;
-    const double* lds = x->hist;
-    for (int w = threadIdx.x; w < words; w += 64)
-        if (lds[w] != 0) atomicAdd(&x->a.hist[w], lds[w]);
-}
-
-// (the pipeline instances carry their rings in LDS and their visit as a call: 3 waves per SIMD at most, also for Euler)
-#define KR_PIPE_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK45 ? 2 : 3, HOG ? KR_HOG_MAX_WAVES : 8)))
-template <int METHOD, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, 64))) KR_PIPE_ATTR
-trace_pipe_kernel(PipeKernArgs ka)
-{
-    if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
-    PipeCtx x;
-    // (the LDS -> generic cast is made here, on the scalar unit: as a vector operation -- in a callee, or feeding a call's argument registers
-    // directly -- this compiler emits an illegal compare against src_shared_base)
-    unsigned long long lds_bits = (unsigned long long) (uintptr_t) static_cast<double*>(pipe_lds);
-    asm volatile("" : "+s"(lds_bits));
-    // (the kernarg pointer is read HERE: asked for in the callee, this compiler's caller does not pass it on and the callee reads a stale register)
-#if __HIP_DEVICE_COMPILE__
-    const __attribute__((address_space(4))) PipeKernArgs* kp = (const __attribute__((address_space(4))) PipeKernArgs*) __builtin_amdgcn_kernarg_segment_ptr();
-    pipe_begin<METHOD, FAST, HOG>(&x, (const PipeKernArgs*) kp, reinterpret_cast<double*>((uintptr_t) lds_bits), HOG ? (long long) blockIdx.x * 64 : -1,       // one wave per workgroup, HOG or not
-                                  HOG ? (unsigned long long) gridDim.x * 64 : 0ull);
-    // The step loop's constants are loaded AFTER that call (the empty asm hides the pointer's origin): loaded at kernel entry, as arguments are,
-    // 18 of them sat in a spill register across the call and came back through ~50 v_readlane per step.
-    asm volatile("" : "+s"(kp));
-    int has_prio = 0;
-    trace_body_pipe<METHOD, FAST, HOG, REFILL_MIN>(&x, *(const TraceConsts<double>*) &kp->c, kp->counters, has_prio);
-#else
-    (void) ka;           // (host pass of the single-source compile: never executed)
-#endif
-    pipe_end<METHOD, FAST, HOG>(&x);
 }
 
 // ONE grid over MANY traces (kr_trace_batch_async_f64 when all traces of the batch use the same kernel instances).  Every wave serves
@@ -747,7 +340,7 @@ trace_pipe_kernel(PipeKernArgs ka)
 // profiles/r02_hw_queues.txt).  (A first version let each wave walk through all traces in turn: every wave then paid the tail of one
 // long ray PER TRACE, 2.9 s for the 18-point sweep instead of 0.6 s.)  Per-ray arithmetic is the single-trace kernel's: same bits.
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
-__global__ void __attribute__((amdgpu_flat_work_group_size(block_of(HOG), block_of(HOG)))) KR_HOG_ATTR
+__global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_WAVES_ATTR
 trace_multi_kernel(const TraceDesc<T>* __restrict__ descs, int n_desc, const int* __restrict__ wave_trace)
 {
     if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
@@ -756,12 +349,11 @@ trace_multi_kernel(const TraceDesc<T>* __restrict__ descs, int n_desc, const int
     const TraceDesc<T>* d = &descs[ti];                           // wave-uniform: scalar loads
     if constexpr (HOG) {
         // (HOG batches map workgroup -> trace by modulo: workgroup b is the (b / n_desc)-th of its trace's gridDim.x / n_desc workgroups)
-        constexpr int kWaves = kHogBlock / 64;
-        const long long g = (long long) (blockIdx.x / (unsigned) n_desc) * kWaves + (threadIdx.x >> 6);
-        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(RecordIO<T>{d->rays}, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio, g * 64,
-                                                               (unsigned long long) (gridDim.x / (unsigned) n_desc) * kWaves * 64);
+        const long long g = (long long) (blockIdx.x / (unsigned) n_desc);
+        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(d->rays, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio, g * 64,
+                                                               (unsigned long long) (gridDim.x / (unsigned) n_desc) * 64);
     } else {
-        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(RecordIO<T>{d->rays}, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio);
+        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(d->rays, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio);
     }
 }
 
@@ -818,19 +410,6 @@ classify_kernel(const kr_ray_f64* __restrict__ rays, long long n, double a, unsi
     strict_mask[i] = classify_append(strict, i, list_strict, n_strict);
 }
 
-// the same for the emissivity pipeline: the ray's constants come from the source, not from memory
-__global__ void __launch_bounds__(kBlock)
-classify_pipe_kernel(EmisPipeArgs args, long long n, double a, unsigned char* __restrict__ strict_mask, int* __restrict__ list_strict,
-                     unsigned long long* __restrict__ n_strict)
-{
-    const long long i = blockIdx.x * (long long) kBlock + threadIdx.x;
-    if (i >= n) return;
-    const kr_ray_f64 ray = pointsource_ray(args.src, args.n_grid, args.n_beta, args.first + i * args.stride);
-    bool strict = false;
-    if (ray.steps >= 0) strict = ill_conditioned(ray.k, ray.h, ray.Q, ray.theta, a);
-    strict_mask[i] = classify_append(strict, i, list_strict, n_strict);
-}
-
 // ---- host side ---------------------------------------------------------------------------------------
 // Everything one trace call needs besides the rays -- queue heads and counters, the strict list and mask, timing events, the
 // second stream of a split launch -- lives in a Workspace taken from a per-device pool for the duration of the call
@@ -846,7 +425,6 @@ struct Workspace {
     int64_t mask_capacity = 0;
     std::vector<void*> retired;                  // outgrown masks (workspace_mask_reserve)
     hipStream_t side_stream = nullptr;                   // the second stream of a split trace: belongs to the caller's stream (side_stream_for)
-    hipStream_t strict_stream = nullptr;                 // KR_CU_PARTITION experiment: the strict side launch's own (CU-masked) stream
     hipEvent_t ev0 = nullptr, ev1 = nullptr;             // the whole trace, caller's stream
     hipEvent_t ev_strict0 = nullptr, ev_strict1 = nullptr; // strict side (+ overflow) launch, caller's stream
     hipEvent_t ev_main0 = nullptr, ev_main1 = nullptr;     // main launch of a split, side stream
@@ -877,22 +455,6 @@ constexpr int kMaxMultiGrid = 32768;                     // single-wave workgrou
 constexpr size_t kMaxSideStreams = 16;
 std::map<hipStream_t, hipStream_t> g_side_streams[64];
 
-// EXPERIMENT (KR_CU_PARTITION=<k>, default off): the strict side launch on a stream whose queue may only use the first k compute units, the main
-// launch on one that may only use the others -- the critical rays' waves then share no CU (instruction cache, scalar cache, issue arbitration)
-// with the main launch's.  Measured: profiles/r03_ab_experiments.txt.
-int cu_partition()
-{
-    static const int k = [] { const char* e = getenv("KR_CU_PARTITION"); return e ? atoi(e) : 0; }();
-    return k;
-}
-hipError_t masked_stream(hipStream_t* s, int first, int count)
-{
-    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = first; i < first + count && i < 256; i++) mask[i / 32] |= 1u << (i % 32);
-    return hipExtStreamCreateWithCUMask(s, 8, mask);
-}
-std::map<hipStream_t, hipStream_t> g_strict_streams[64];
-
 int side_stream_for(int dev, hipStream_t user, hipStream_t* out)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -907,19 +469,8 @@ int side_stream_for(int dev, hipStream_t user, hipStream_t* out)
         }
         int least = 0, greatest = 0;
         KR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        int prio = least;
-        if (const char* e = getenv("KR_SIDE_STREAM_PRIORITY")) prio = !strcmp(e, "high") ? greatest : !strcmp(e, "default") ? 0 : least;
         hipStream_t s = nullptr;
-        if (cu_partition() > 0) {
-            int cus = 0;
-            KR_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            KR_HIP(masked_stream(&s, cu_partition(), cus - cu_partition()));
-            hipStream_t st = nullptr;
-            KR_HIP(masked_stream(&st, 0, cu_partition()));
-            g_strict_streams[dev][user] = st;
-        } else {
-            KR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
-        }
+        KR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
         it = table.emplace(user, s).first;
     }
     *out = it->second;
@@ -1067,7 +618,6 @@ struct ListArgs {
     const unsigned char* mask = nullptr;          // per-ray launch selector, or null
     int mask_want = 0;
     int fixed_grid = 0;                           // > 0: launch exactly this many workgroups
-    const EmisPipeArgs* pipe = nullptr;           // emissivity pipeline: rays are generated / reduced in the kernel (no records; `rays` is unused)
 };
 
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG = false>
@@ -1081,7 +631,7 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
     int blocks_per_cu = occ.load(std::memory_order_relaxed);
     if (blocks_per_cu == 0) {
         int v = 0;
-        KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, block_of(HOG), 0));
+        KR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, kern, kTraceBlock, 0));
         blocks_per_cu = v < 1 ? 1 : v;
         occ.store(blocks_per_cu, std::memory_order_relaxed);
     }
@@ -1097,24 +647,13 @@ int launch(typename RayOf<T>::type* rays, int64_t n, const TraceConsts<T>& c, un
         const int v = atoi(e);
         if (v >= 1) want = v;
     }
-    want *= 4 / kWavesPerBlock;                 // `want` counts 256-thread workgroups (= waves per SIMD)
+    want *= 4;                                  // `want` counts waves per SIMD; a workgroup is one wave, a CU has four SIMDs
     if (want < blocks_per_cu) blocks_per_cu = want;
     const int64_t resident = (int64_t) cus * blocks_per_cu;
     const int64_t wanted = (n + kTraceBlock - 1) / kTraceBlock;
     int grid = (int) std::max<int64_t>(1, std::min(resident, wanted));
     if (la.fixed_grid > 0) grid = la.fixed_grid;
-    if constexpr (std::is_same<T, double>::value && !USE_DEST) {
-        if (la.pipe) {
-            static_assert(kHogBlock == 64, "the pipeline instances run one wave per workgroup (their LDS rings belong to a wave)");
-            const size_t lds = PipeRings::bytes(la.pipe->use_lds ? 5 * la.pipe->bins.nr + 1 : 0);
-            const PipeKernArgs ka{*la.pipe, (long long) n, c, counters, la.list, la.n_ptr, la.mask, la.n_mode, la.mask_want};
-            hipLaunchKernelGGL((trace_pipe_kernel<METHOD, FAST, HOG, kRefill>), dim3(grid), dim3(64), lds, stream, ka);
-            KR_HIP(hipGetLastError());
-            return KR_OK;
-        }
-    }
-    if (la.pipe) { set_error("kr_trace: the pipeline instances exist for the double-precision theta-limit overloads only"); return KR_EINVAL; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block_of(HOG)), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.n_mode, la.mask, la.mask_want);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTraceBlock), 0, stream, rays, (long long) n, c, counters, la.list, la.n_ptr, la.n_mode, la.mask, la.mask_want);
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
@@ -1142,7 +681,7 @@ int launch_multi(const TraceDesc<T>* d_descs, int n_desc, const int* d_wave_trac
 {
     constexpr int kRefill = KR_REFILL_MIN;
     auto kern = trace_multi_kernel<T, METHOD, USE_DEST, FAST, HOG, kRefill>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block_of(HOG)), 0, stream, d_descs, n_desc, d_wave_trace);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kTraceBlock), 0, stream, d_descs, n_desc, d_wave_trace);
     KR_HIP(hipGetLastError());
     return KR_OK;
 }
@@ -1171,7 +710,7 @@ int launch_multi_f64(int integrator, bool dest, const TraceDesc<double>* d, int 
 // empty leave at once); a source made mostly of ill-conditioned rays (all rays in one meridional plane, say) overflows the
 // list, and the overflow -- mask value 2 -- is traced by a third, ordinary-occupancy strict launch that is a no-op otherwise
 // (its workgroups read the count and leave).
-int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream, const EmisPipeArgs* pipe = nullptr)
+int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream)
 {
     if (n > 0x7fffffff) { set_error("kr_trace: the split path indexes rays with 32 bits"); return KR_EINVAL; }
     {
@@ -1181,33 +720,25 @@ int split_front(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wo
     unsigned long long* split_words = ws->counters + 3 * kCounters;     // [1] n_strict (zeroed by the caller's memset)
     const TraceConsts<double> c = make_consts<double>(p, steplim);
     const int cgrid = (int) ((n + kBlock - 1) / kBlock);
-    if (pipe) hipLaunchKernelGGL(classify_pipe_kernel, dim3(cgrid), dim3(kBlock), 0, stream, *pipe, (long long) n, p->spin, ws->mask, ws->list, split_words + 1);
-    else hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, ws->mask, ws->list, split_words + 1);
+    hipLaunchKernelGGL(classify_kernel, dim3(cgrid), dim3(kBlock), 0, stream, rays, (long long) n, p->spin, ws->mask, ws->list, split_words + 1);
     KR_HIP(hipGetLastError());
     KR_HIP(hipEventRecord(ws->ev_classified, stream));
-    hipStream_t caller = stream;
-    if (ws->strict_stream) {
-        stream = ws->strict_stream;
-        KR_HIP(hipStreamWaitEvent(stream, ws->ev_classified, 0));
-    }
     KR_HIP(hipEventRecord(ws->ev_strict0, stream));
     // strict side launch: one wave, alone on its SIMD, per 64 listed rays, on at most half of the chip
     ListArgs strict_la;
     strict_la.list = ws->list;
     strict_la.n_ptr = split_words + 1;
     strict_la.n_mode = 1;
-    strict_la.pipe = pipe;
     const int64_t list_max = std::min<int64_t>(n, kListCap);
-    strict_la.fixed_grid = (int) std::max<int64_t>(1, std::min<int64_t>((list_max + kHogBlock - 1) / kHogBlock, (int64_t) (ws->cus / 2) * (256 / kHogBlock)));
+    strict_la.fixed_grid = (int) std::max<int64_t>(1, std::min<int64_t>((list_max + kTraceBlock - 1) / kTraceBlock, (int64_t) (ws->cus / 2) * 4));
     const int rc = launch_f64<false, true>(p, rays, list_max, c, ws->counters + kCounters, ws->cus, stream, 1, strict_la);
     if (rc != KR_OK) return rc;
     KR_HIP(hipEventRecord(ws->ev_strict1, stream));
-    if (ws->strict_stream) KR_HIP(hipStreamWaitEvent(caller, ws->ev_strict1, 0));
     ws->split = true;
     return KR_OK;
 }
 
-int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream, bool fast_main, const EmisPipeArgs* pipe = nullptr)
+int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Workspace* ws, hipStream_t stream, bool fast_main)
 {
     unsigned long long* split_words = ws->counters + 3 * kCounters;
     const TraceConsts<double> c = make_consts<double>(p, steplim);
@@ -1218,7 +749,6 @@ int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wor
     ListArgs main_la;
     main_la.mask = ws->mask;
     main_la.mask_want = 0;
-    main_la.pipe = pipe;
     const int main_waves = mb ? mb : (fast_main && p->integrator == KR_EULER) ? 4 : 3;      // resident waves per SIMD of the main launch
     int rc = fast_main ? launch_f64<true, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, main_waves, main_la)
                        : launch_f64<false, false>(p, rays, n, c, ws->counters, ws->cus, ws->side_stream, main_waves, main_la);
@@ -1232,7 +762,6 @@ int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wor
         rest_la.n_mode = 2;
         rest_la.mask = ws->mask;
         rest_la.mask_want = 2;
-        rest_la.pipe = pipe;
         rc = launch_f64<false, false>(p, rays, n, c, ws->counters + 2 * kCounters, ws->cus, ws->side_stream, mb, rest_la);
         if (rc != KR_OK) return rc;
     }
@@ -1242,10 +771,9 @@ int split_back(const kr_params* p, kr_ray_f64* rays, int64_t n, int steplim, Wor
 }
 
 template <typename T>
-int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned long long* counters, int cus, hipStream_t stream, const EmisPipeArgs* pipe = nullptr)
+int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned long long* counters, int cus, hipStream_t stream)
 {
     ListArgs la;
-    la.pipe = pipe;
     using R = typename RayOf<T>::type;
     R* rays = (R*) d_rays;
     const TraceConsts<T> c = make_consts<T>(p, steplim);
@@ -1275,9 +803,9 @@ int dispatch(const kr_params* p, void* d_rays, int64_t n, int steplim, unsigned 
     }
 }
 
-int validate(const kr_params* p, void* d_rays, int64_t n, bool rays_needed = true)
+int validate(const kr_params* p, void* d_rays, int64_t n)
 {
-    if (p && n > 0 && !d_rays && rays_needed) { set_error("kr_trace: null argument or negative n"); return KR_EINVAL; }
+    if (p && n > 0 && !d_rays) { set_error("kr_trace: null argument or negative n"); return KR_EINVAL; }
     if (!p || n < 0) { set_error("kr_trace: null argument or negative n"); return KR_EINVAL; }
     if (p->integrator < KR_EULER || p->integrator > KR_RK45) { set_error("kr_trace: unknown integrator"); return KR_EINVAL; }
     if (p->stop_kind < KR_STOP_THETA || p->stop_kind > KR_STOP_FLATPLANE) { set_error("kr_trace: unknown stop_kind"); return KR_EINVAL; }
@@ -1303,12 +831,11 @@ struct Pending {
     bool f32 = false, hybrid = false, split = false;
     int steplim = 0;
     Workspace* ws = nullptr;
-    const EmisPipeArgs* pipe = nullptr;       // emissivity pipeline (trace_pipeline_emis): no ray records
 };
 
 int trace_front(Pending& t, bool batch)
 {
-    int rc = validate(t.p, t.d_rays, t.n, t.pipe == nullptr);
+    int rc = validate(t.p, t.d_rays, t.n);
     if (rc != KR_OK) return rc;
     if (t.n == 0) return KR_OK;
     // effective_steplim, raytracer.cpp:80
@@ -1329,13 +856,7 @@ int trace_front(Pending& t, bool batch)
     if (t.split) {
         rc = side_stream_for(ws->device, t.stream, &ws->side_stream);
         if (rc != KR_OK) return rc;
-        ws->strict_stream = nullptr;
-        if (cu_partition() > 0) {
-            std::lock_guard<std::mutex> lk(g_mu);
-            auto it = g_strict_streams[ws->device].find(t.stream);
-            if (it != g_strict_streams[ws->device].end()) ws->strict_stream = it->second;
-        }
-        return split_front(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream, t.pipe);
+        return split_front(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream);
     }
     return KR_OK;
 }
@@ -1345,8 +866,8 @@ int trace_back(Pending& t)
     if (t.n == 0 || !t.ws) return KR_OK;
     Workspace* ws = t.ws;
     int r = t.f32 ? dispatch<float>(t.p, t.d_rays, t.n, t.steplim, ws->counters, ws->cus, t.stream)
-                  : t.split ? split_back(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream, t.hybrid, t.pipe)
-                            : dispatch<double>(t.p, t.d_rays, t.n, t.steplim, ws->counters, ws->cus, t.stream, t.pipe);
+                  : t.split ? split_back(t.p, (kr_ray_f64*) t.d_rays, t.n, t.steplim, ws, t.stream, t.hybrid)
+                            : dispatch<double>(t.p, t.d_rays, t.n, t.steplim, ws->counters, ws->cus, t.stream);
     if (r != KR_OK) return r;
     KR_HIP(hipEventRecord(ws->ev1, t.stream));
     KR_HIP(hipMemcpyAsync(ws->h_counters, ws->counters, kCounterBlocks * kCounters * sizeof(unsigned long long), hipMemcpyDeviceToHost, t.stream));
@@ -1481,8 +1002,7 @@ int merged_batch(std::vector<Pending>& ts, bool hybrid)
     // in total (1024 SIMDs; at least 4 per trace) -- a wave refills from its trace's list, so fewer waves only mean more rays per wave,
     // whereas thousands of exclusive single-wave workgroups that find nothing to do still have to be placed one by one
     const int64_t hog_per_trace = std::max<int64_t>(4, std::min<int64_t>(hog_max, (4 * (int64_t) w0->cus) / count));            // waves
-    const int64_t hog_wgs_per_trace = (hog_per_trace * 64 + kHogBlock - 1) / kHogBlock;                                          // workgroups
-    rc = launch_multi_f64<false, true>(p0->integrator, dest, d, count, nullptr, (int) (hog_wgs_per_trace * count), primary);
+    rc = launch_multi_f64<false, true>(p0->integrator, dest, d, count, nullptr, (int) (hog_per_trace * count), primary);
     if (rc != KR_OK) return rc;
     for (auto& t : ts) KR_HIP(hipEventRecord(t.ws->ev_strict1, primary));
     KR_HIP(hipStreamWaitEvent(side, w0->ev_classified, 0));
@@ -1639,32 +1159,10 @@ int trace_shutdown()
         for (auto& kv : g_side_streams[dev])
             if (std::find(seen.begin(), seen.end(), kv.second) == seen.end()) { seen.push_back(kv.second); (void) hipStreamDestroy(kv.second); }
         g_side_streams[dev].clear();
-        for (auto& kv : g_strict_streams[dev]) (void) hipStreamDestroy(kv.second);
-        g_strict_streams[dev].clear();
     }
     if (have_dev) (void) hipSetDevice(keep);
     (void) hipGetLastError();
     return KR_OK;
-}
-
-// The emissivity pipeline (kr_emissivity_pipeline_dev_f64): source -> redshift_start -> run_raytrace -> redshift -> radial histogram as ONE trace
-// (classification + side launch + main launch like any other; trace_body_pipe), the rays living in registers and LDS from birth to bin.
-int trace_pipeline_emis(const kr_params* p, const EmisPipeArgs* args, int64_t n, hipStream_t stream, kr_stats* stats)
-{
-    if (stats) { std::memset(stats, 0, sizeof(*stats)); stats->rays_total = n; }
-    if (!args || !args->hist) { set_error("kr_emissivity_pipeline: null argument"); return KR_EINVAL; }
-    if (p && (p->stop_kind != KR_STOP_THETA)) { set_error("kr_emissivity_pipeline: theta-limit overload only"); return KR_EINVAL; }
-    Pending t;
-    t.p = p; t.d_rays = nullptr; t.n = n; t.stream = stream; t.f32 = false; t.pipe = args;
-    int rc = trace_front(t, false);
-    if (rc == KR_OK) rc = trace_back(t);
-    if (rc != KR_OK) { abandon(t); return rc; }
-    void* ticket = nullptr;
-    hand_over(t, &ticket);
-    if (!stats) { trace_release(ticket); return KR_OK; }
-    const int rc2 = trace_wait(ticket, stats);
-    stats->rays_total = n;
-    return rc2;
 }
 
 int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, kr_stats* stats, bool f32)
