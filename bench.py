@@ -137,14 +137,47 @@ def omp_set_threads(n):
         return False
 
 
-def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
+def device_pipeline_histogram(lib, capi, api, spec, p, bins):
+    """The device-resident pipeline bench.py times (device PointSource + redshift_start -> trace -> range_phi + redshift + histogram; the fused
+    passes) once on `spec`: returns (histogram words, kr_stats)."""
+    import torch
+    n = api.pointsource_count(spec)[0]
+    rays = torch.empty(n * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda")
+    res = torch.zeros(5 * bins.nr + 1, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    vp = C.c_void_p
+    capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(spec), 0, 1, 0.0, 0, 0, vp(rays.data_ptr()), n, vp(stream)), "init_emit")
+    st = api.trace_dev(p, rays.data_ptr(), n, stream=stream, want_stats=True)
+    capi.check(lib, lib.kr_post_emissivity_dev_f64(SPIN, -1.0, 0, 0, 0, -math.pi, math.pi, C.byref(bins), vp(rays.data_ptr()), n, vp(res.data_ptr()), vp(stream)), "post")
+    torch.cuda.synchronize()
+    return res.cpu().numpy(), st
+
+
+def histogram_check(h, nr, cnt, flux, emis, sg, stt, disc_count):
+    """Device histogram words h = [count | flux | emis | sum_redshift | sum_time | disc_count] against the CPU reducer's arrays."""
+    got_cnt = np.rint(h[:nr]).astype(np.int64)
+    same = got_cnt == cnt
+    worst, excluded_sum_bins = 0.0, int((~same & (cnt > 0)).sum())
+    for k, w in enumerate((flux, emis, sg, stt)):
+        g = h[(k + 1) * nr:(k + 2) * nr]
+        m = same & (cnt > 0)
+        if m.any():
+            worst = max(worst, float(np.max(np.abs(g[m] - w[m]) / np.abs(w[m]))))
+    return {"bins": int(nr), "bins_count_mismatch": int((~same).sum()), "max_count_diff": int(np.abs(cnt - got_cnt).max()), "max_rel_diff_on_matching_bins": worst,
+            "bins_excluded_from_the_sum_check": excluded_sum_bins, "disc_rays_device": int(round(float(h[5 * nr]))), "disc_rays_cpu": int(disc_count), "tolerance": 1e-6}
+
+
+def cpu_baseline(args, capi, api, integrator, d_full, flags=0, timed=None):
     """Times the CPU path on this box's host cores -- the reference's own run_raytrace (oracle/_ref) where it was built, else the oracle port --
     and checks the GPU results ray by ray and bin by bin against it.  Two legs:
       * thread sweep: the reference's `omp parallel for schedule(dynamic)` with an `omp atomic` progress counter (raytracer.cpp:104-124) does not
         scale to every hardware thread of a 256-thread host, so a ~1e6-ray sample of the workload is timed at 16 / 32 / 64 / 128 / 256 threads (those the
         box has) and the best team size is kept;
       * the headline grid ITSELF (3162^2 rays, what `value` of the GPU line is quoted on) at that team size -- unless the sweep says it would take
-        more than ~90 s, or --cpu-sample-rays asks for a sample; the checks then run on the same rays the timing ran on."""
+        more than ~90 s, or --cpu-sample-rays asks for a sample; the checks then run on the same rays the timing ran on.
+    Three checks against that CPU run: `pipeline_bins_check` -- the histogram and step total of the TIMED device-resident pipeline itself (timed =
+    {"hist", "steps"} of the last timed pass; device-built rays, fused passes), or of one more run of that pipeline on the sample grid when the CPU
+    leg ran on a sample; `bins_check` and `rays_check` -- the reference-constructed rays traced through the host-pointer entry points."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol   # bench.py's cpu_baseline leg is one of the three places allowed to touch oracle/
     cores = os.cpu_count() or 1
@@ -211,6 +244,15 @@ def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
     flux, emis, sg, stt = (np.zeros(nr) for _ in range(4))
     dc = C.c_int64()
     o.kro_reduce_emissivity_f64(C.byref(bins), ol.ptr(cpu_rays), len(cpu_rays), ol.ptr(cnt), ol.ptr(flux), ol.ptr(emis), ol.ptr(sg), ol.ptr(stt), C.byref(dc))
+    # ... and the pipeline bench.py TIMES: device-built rays (kr_pointsource_init_emit_dev_f64), fused passes, histogram left in HBM
+    if on_headline_grid and timed is not None:
+        pipe_h, pipe_steps, pipe_what = timed["hist"], int(timed["steps"]), "the last TIMED pass itself"
+    else:
+        pipe_h, pst = device_pipeline_histogram(api.lib(), capi, api, spec, p, bins)
+        pipe_steps, pipe_what = int(pst["steps_total"]), "one more run of the timed pipeline, on the CPU leg's sample grid"
+    pipeline_bins_check = histogram_check(pipe_h, nr, cnt, flux, emis, sg, stt, dc.value)
+    pipeline_bins_check.update({"what": pipe_what + ": device PointSource + redshift_start -> trace -> range_phi + redshift + histogram, against the reference's constructor + run_raytrace "
+                                "+ the oracle's O(N) passes and reducer on the same grid", "rk_steps_device": pipe_steps, "rk_steps_cpu": steps, "rk_steps_equal": pipe_steps == steps})
     same = cnt == got["count"]
     worst = 0.0
     for k, w in (("flux", flux), ("emis", emis), ("sum_redshift", sg), ("sum_time", stt)):
@@ -227,8 +269,18 @@ def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
         for k in ("r", "theta", "redshift"):
             close &= ~(np.abs(gpu_rays[k] - cpu_rays[k]) > 1e-9 * np.maximum(np.abs(cpu_rays[k]), 1e-300))
     on_disc = valid & ((cpu_rays["status"] & 1) != 0)
+
+    def worst_rel(mask):
+        w = 0.0
+        with np.errstate(invalid="ignore"):
+            for k in ("r", "theta", "redshift"):
+                d = np.abs(gpu_rays[k][mask] - cpu_rays[k][mask]) / np.maximum(np.abs(cpu_rays[k][mask]), 1e-300)
+                if len(d):
+                    w = max(w, float(np.nanmax(d)))
+        return w
     rays_check = {"rays": n_valid, "integer_fields_differ": int((valid & ~ints_same).sum()),
                   "disc_rays": int(on_disc.sum()), "disc_rays_beyond_1e-9": int((on_disc & ints_same & ~close).sum()),
+                  "disc_rays_worst_rel_diff(r, theta, redshift)": worst_rel(on_disc & ints_same),
                   "bit_identical_r_theta_frac": float(((gpu_rays["r"] == cpu_rays["r"]) & (gpu_rays["theta"] == cpu_rays["theta"]))[valid].mean())}
     # the same sample once more on the strict arithmetic (IEEE + - x / sqrt, correctly rounded sin / cos): how many rays carry the CPU's bits
     # in EVERY output of the trace + redshift (what the hybrid launch gives its flagged rays; all rays with --arithmetic strict)
@@ -251,8 +303,9 @@ def cpu_baseline(args, capi, api, integrator, d_full, flags=0):
                   f"OpenMP team of {best} threads = the best of the sweep below",
         "steps_per_sec": steps / wall, "wall_s": wall, "rays_per_sec_per_thread": n_valid / wall / best,
         "thread_sweep": {"what": f"run_raytrace on a {sweep[best]['rays']}-ray sample of the same source at each team size", "teams": {str(t): v for t, v in sweep.items()}},
+        "pipeline_bins_check": pipeline_bins_check,
         "bins_check": {"bins": int(nr), "bins_count_mismatch": int((~same).sum()), "max_count_diff": int(np.abs(cnt - got["count"]).max()),
-                       "max_rel_diff_on_matching_bins": worst, "tolerance": 1e-6},
+                       "max_rel_diff_on_matching_bins": worst, "bins_excluded_from_the_sum_check": int((~same & (cnt > 0)).sum()), "tolerance": 1e-6},
         "rays_check": rays_check,
     }
 
@@ -789,7 +842,7 @@ def main():
         if world > 1:
             pass                                    # cpu_baseline is an N = 1 leg only
         elif not args.no_cpu_baseline and args.workload == "emissivity":
-            out["cpu_baseline"] = cpu_baseline(args, capi, api, wl.method, wl.d, mode_flags[args.arithmetic])
+            out["cpu_baseline"] = cpu_baseline(args, capi, api, wl.method, wl.d, mode_flags[args.arithmetic], timed={"hist": h, "steps": steps_total})
         elif not args.no_cpu_baseline and args.workload == "imageplane":
             out["cpu_baseline"] = cpu_baseline_imageplane(args, capi, api, wl)
         print(json.dumps(out), flush=True)
@@ -877,13 +930,36 @@ def cpu_baseline_imageplane(args, capi, api, wl):
     for k in ("status", "rdot_flips", "equatorial_crossings", "steps"):
         bits &= strict[k] == out[k]
     strict_bits = float(bits[live].mean())
-    planes_check = {"image": f"{img}x{img}", "lit_pixels": int((w_n > 0).sum()), "pixels_count_mismatch": int((~same).sum()), "disc_rays_cpu": int(dc.value),
-                    "disc_rays_gpu": int(got["disc_count"]), "max_rel_diff_of_pixel_sums(RADIUS, ENSHIFT, FLUX, TIME)": worst, "tolerance": 1e-6,
-                    "ray_integer_fields_differ": ints_differ,
-                    "strict_arithmetic_bit_identical_frac(t, r, theta, phi, redshift, integer fields)": strict_bits}
+    # ... and the pipeline bench.py TIMES, on this coarser grid: device-built rays (kr_imageplane_init_emit_runs_dev_f64), fused passes, planes left in HBM.
+    # The device constructor's acos / asin / atan2 / tan are not glibc's on every ray, so a ray next to a pixel or disc edge may land
+    # on the other side: reported, not hidden.
+    import torch
+    lib, vp = api.lib(), C.c_void_p
+    n_dev = api.imageplane_count(spec)[0]
+    d_rays = torch.empty(n_dev * capi.RAY_F64.itemsize, dtype=torch.uint8, device="cuda")
+    d_res = torch.zeros(7 * npix + 1, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    capi.check(lib, lib.kr_imageplane_init_emit_runs_dev_f64(C.byref(spec), 0, 1, 1, 0.0, 1, 0, vp(d_rays.data_ptr()), n_dev, vp(stream)), "init_emit")
+    pst = api.trace_dev(p, d_rays.data_ptr(), n_dev, stream=stream, want_stats=True)
+    capi.check(lib, lib.kr_post_image_dev_f64(-SPIN, -1.0, 1, 0, 0, -math.pi, math.pi, C.byref(b), vp(d_rays.data_ptr()), n_dev, vp(d_res.data_ptr()), vp(stream)), "post")
+    torch.cuda.synchronize()
+    hp = d_res.cpu().numpy()
+    dev_planes = api.image_planes_from_words(hp, img, img)
+    psame = dev_planes["nrays"] == w_n
+    pworst = {}
+    for k in ("r", "enshift", "flux", "time"):
+        m = psame & (w_n > 0)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            pworst[k] = float(np.max(np.abs(dev_planes[k][m] - w_pl[k][m]) / np.abs(w_pl[k][m]))) if m.any() else 0.0
+    pipeline_planes_check = {
+        "what": "one run of the timed pipeline (device ImagePlane + redshift_start -> trace -> redshift + range_phi + planes) on the CPU leg's grid",
+        "pixels_count_mismatch": int((~psame).sum()), "pixels_excluded_from_the_sum_check": int((~psame & (w_n > 0)).sum()),
+        "max_count_diff": int(np.abs(dev_planes["nrays"].astype(np.int64) - w_n).max()),
+        "disc_rays_device": int(round(float(hp[-1]))), "disc_rays_cpu": int(dc.value), "max_rel_diff_of_pixel_sums(RADIUS, ENSHIFT, FLUX, TIME)": pworst,
+        "rk_steps_device": int(pst["steps_total"]), "rk_steps_cpu": steps, "tolerance": 1e-6}
     return {"value": int(live.sum()) / wall, "unit": "rays/s", "cores": cores, "kind": kind, "steps_per_sec": steps / wall, "wall_s": wall,
             "sample": f"same image plane on a {N + 1}x{N + 1} ray grid: {int(live.sum())} rays, {steps} steps, run_raytrace only",
-            "planes_check": planes_check}
+            "pipeline_planes_check": pipeline_planes_check, "planes_check": planes_check}
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define KR_ABI_VERSION 14
+#define KR_ABI_VERSION 15
 
 /* error codes */
 #define KR_OK          0
@@ -223,6 +223,12 @@ double      kr_kerr_isco(double a, int sign);               /* kerr_isco(), kerr
 double      kr_disc_velocity(double r, double a, int sign); /* disc_velocity(), kerr.h:35-38 */
 int64_t     kr_pointsource_count(const kr_pointsource* s, int32_t* n_cosalpha, int32_t* n_beta);   /* pointsource.cpp:12,16-17 */
 int64_t     kr_imageplane_count(const kr_imageplane* s, int32_t* nx, int32_t* ny);                 /* imageplane.cpp:12-14 */
+/* The transcendental values of the PointSource constructor (pointsource.cpp:38-46: alpha = acos(cosalpha0 + i dcosalpha), beta = beta0 + j dbeta;
+ * raytracer.cpp:631-672: sin / cos of alpha and beta, sin / cos / tan of the source's polar angle pos[2]) computed on the HOST with the C library
+ * the reference calls.  The device constructors (kr_pointsource_init*_dev_f64) read exactly these -- they upload them once per (device, grid) and
+ * keep them until kr_shutdown -- so k, h, Q of a device-built ray carry the reference constructor's bits.  Needs no GPU.
+ * alpha_sincos: 2 * n_cosalpha doubles (sin, cos interleaved); beta_sincos: 2 * n_beta; pos_sin_cos_tan: 3.  Any of them may be NULL. */
+int         kr_pointsource_tables(const kr_pointsource* s, double* alpha_sincos, double* beta_sincos, double* pos_sin_cos_tan);
 
 /* ---- the hot path: Raytracer<T>::run_raytrace, both overloads (raytracer.cpp:63-127, 972-1034) --
  * Host-pointer forms stage through a private device buffer and return when rays[] is final.  *_dev forms take a device
@@ -257,6 +263,15 @@ int kr_trace_wait(void* ticket, kr_stats* stats);
  * released, also when one of them fails (the first error code is returned). */
 int kr_trace_wait_many(int32_t count, void* const* tickets, kr_stats* per_ticket, kr_stats* total);
 int kr_trace_release(void* ticket);
+/* Progress of a trace in flight (run_raytrace's show_progress, raytracer.cpp:84-85, :107-115: a counter of rays whose loop iteration has STARTED).
+ * kr_trace_poll: how many rays the trace behind `ticket` has taken off its work queue so far and whether it has finished; it neither waits nor
+ * retires the ticket (an 8-byte DMA read of the queue head on a stream of the library's own: it completes while the trace kernels hold every SIMD).
+ * kr_trace_progress_*: kr_trace_* (host pointers) which, while the trace runs, polls every 20 ms on the calling thread and calls
+ * fn(rays_started rounded down to a multiple of `every`, n, user) each time a new multiple has been passed.  every <= 0 or fn == NULL: no calls. */
+typedef void (*kr_progress_fn)(int64_t rays_started, int64_t rays_total, void* user);
+int kr_trace_poll(void* ticket, int64_t* rays_started, int32_t* finished);
+int kr_trace_progress_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, kr_stats* stats, int64_t every, kr_progress_fn fn, void* user);
+int kr_trace_progress_f32(const kr_params* p, kr_ray_f32* rays, int64_t n, kr_stats* stats, int64_t every, kr_progress_fn fn, void* user);
 
 /* ---- O(N) passes either side of it ----------------------------------------------------------- */
 /* Raytracer<T>::redshift_start(V, reverse, projradius)  raytracer.cpp:342-417 */
@@ -387,12 +402,16 @@ int kr_stream_destroy(void* stream);                /* also releases the interna
 /* Hardware queues.  Traces are meant to overlap (a split trace uses two streams, a multi-launch driver keeps many in flight) and the
  * HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues per device -- 4 by default: 18 concurrent RK45 sweep points take
  * 1.65 s on 4 queues, 0.76 s on 16 (profiles/r02_hw_queues.txt).  The variable is read when the runtime initialises, and it is
- * process-global: the library does NOT touch it.  An application that owns its process calls kr_configure_process() FIRST (before any
- * other HIP user -- this library, PyTorch, RCCL -- starts the runtime); it sets GPU_MAX_HW_QUEUES=16 unless the user chose a value and
- * returns 1, or returns 0 and changes nothing when the runtime is already up.  (bench.py, the kr_* apps and the class mirror call it.) */
+ * process-global: the library does NOT touch it when it is loaded.  An application that owns its process calls kr_configure_process() FIRST (before
+ * any other HIP user -- this library, PyTorch, RCCL -- starts the runtime); it sets GPU_MAX_HW_QUEUES=16 unless the user chose a value.
+ * Returns 1 if it set (or found) the variable before THIS LIBRARY touched the runtime, 0 if this library already had: it cannot see whether another
+ * HIP user in the process (PyTorch, RCCL) started the runtime earlier -- then the setting comes too late and 1 is returned all the same.  The Python
+ * package sets the default in raytrace_cpu_amd/__init__.py, i.e. at import, before `import torch` can start the runtime; bench.py, the kr_* apps
+ * and the class mirror call this function first thing. */
 int kr_configure_process(void);
-/* Waits for the devices the library has used, then releases every pooled trace workspace and internal stream (outstanding tickets
- * become invalid).  Optional, and never done implicitly: at process exit the HIP runtime may already be gone when this library is unloaded. */
+/* Waits for the devices the library has used, then releases every pooled trace workspace, internal stream and PointSource table.  Refused with
+ * KR_EINVAL (nothing released) while a ticket of kr_trace_async_* / kr_trace_batch_async_f64 is outstanding: wait for or release the tickets first.
+ * Optional, and never done implicitly: at process exit the HIP runtime may already be gone when this library is unloaded. */
 int kr_shutdown(void);
 
 #ifdef __cplusplus

@@ -181,3 +181,14 @@ def reduce_image(bins, rays):
     out = {"nrays": nrays, "disc_count": dc.value}
     out.update(planes)
     return out
+
+
+def image_planes_from_words(words, nx, ny):
+    """The device-resident reducers' result buffer (kr_reduce_image_dev_f64 / kr_post_image_dev_f64: 7 nx ny + 1 doubles,
+    [nrays | flux | r | phi | enshift | time | emis | disc_count]) as the dict reduce_image() returns."""
+    npix = nx * ny
+    words = np.asarray(words)
+    out = {"nrays": np.rint(words[:npix]).astype(np.int32), "disc_count": int(round(float(words[7 * npix])))}
+    for q, k in enumerate(("flux", "r", "phi", "enshift", "time", "emis")):
+        out[k] = words[(q + 1) * npix:(q + 2) * npix]
+    return out

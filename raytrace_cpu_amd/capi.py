@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 KR_OK, KR_EINVAL, KR_ENODEVICE, KR_EHIP, KR_ENOMEM = 0, -1, -2, -3, -4
 EULER, RK4, RK45 = 0, 1, 2
@@ -98,6 +98,7 @@ def copy_params(p, **kw):
 
 P = C.POINTER
 _vp, _i64, _i32, _dbl, _int = C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)      # kr_progress_fn
 
 # name -> (restype, argtypes); exactly the entry points include/kr_trace.h declares
 PROTOTYPES = {
@@ -154,6 +155,10 @@ PROTOTYPES = {
     "kr_imageplane_init_emit_dev_f64": (_int, [P(ImagePlaneSpec), _i64, _i64, _dbl, _int, _int, _vp, _i64, _vp]),
     "kr_imageplane_init_emit_runs_dev_f64": (_int, [P(ImagePlaneSpec), _i64, _i64, _i64, _dbl, _int, _int, _vp, _i64, _vp]),
     "kr_post_image_dev_f64": (_int, [_dbl, _dbl, _int, _int, _int, _dbl, _dbl, P(ImageBins), _vp, _i64, _vp, _vp]),
+    "kr_trace_poll": (_int, [_vp, P(_i64), P(_i32)]),
+    "kr_trace_progress_f64": (_int, [P(Params), _vp, _i64, P(Stats), _i64, PROGRESS_FN, _vp]),
+    "kr_trace_progress_f32": (_int, [P(Params), _vp, _i64, P(Stats), _i64, PROGRESS_FN, _vp]),
+    "kr_pointsource_tables": (_int, [P(PointSourceSpec), _vp, _vp, _vp]),
     "kr_post_emissivity_dev_f64": (_int, [_dbl, _dbl, _int, _int, _int, _dbl, _dbl, P(EmisBins), _vp, _i64, _vp, _vp]),
     "kr_reduce_image_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(_i64)]),
     "kr_reduce_image_dev_f64": (_int, [P(ImageBins), _vp, _i64, _vp, _vp]),

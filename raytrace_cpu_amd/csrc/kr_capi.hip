@@ -291,6 +291,18 @@ int64_t kr_pointsource_count(const kr_pointsource* s, int32_t* n_cosalpha, int32
     return nrays;
 }
 
+// What the device PointSource constructor reads instead of calling acos / sin / cos / tan itself (kr_post_device.hpp::SourceTables): host values.
+int kr_pointsource_tables(const kr_pointsource* s, double* alpha_sincos, double* beta_sincos, double* pos_sin_cos_tan)
+{
+    if (!s) { set_error("kr_pointsource_tables: null spec"); return KR_EINVAL; }
+    int32_t nc = 0, nb = 0;
+    kr_pointsource_count(s, &nc, &nb);
+    if (alpha_sincos) angle_values(0, s->cosalpha0, s->dcosalpha, nc, alpha_sincos);
+    if (beta_sincos) angle_values(1, s->beta0, s->dbeta, nb, beta_sincos);
+    if (pos_sin_cos_tan) { ::sincos(s->pos[2], &pos_sin_cos_tan[0], &pos_sin_cos_tan[1]); pos_sin_cos_tan[2] = std::tan(s->pos[2]); }
+    return KR_OK;
+}
+
 // imageplane.cpp:12-14
 int64_t kr_imageplane_count(const kr_imageplane* s, int32_t* nx, int32_t* ny)
 {
@@ -374,6 +386,50 @@ int kr_trace_f32(const kr_params* p, kr_ray_f32* rays, int64_t n, kr_stats* stat
     if (stats) std::memset(stats, 0, sizeof(*stats));
     return with_staged_rays(rays, n, sizeof(kr_ray_f32), true, true, stats,
                             [&](void* d) { return trace_dev(p, d, n, nullptr, stats, true); });
+}
+
+// run_raytrace with show_progress != 0 (raytracer.cpp:84-85, :107-115): the same trace, and while it runs the calling thread polls the work
+// queue and reports every multiple of `every` rays it sees passed
+namespace {
+int trace_with_progress(const kr_params* p, void* d, int64_t n, bool f32, kr_stats* stats, int64_t every, kr_progress_fn fn, void* user)
+{
+    void* ticket = nullptr;
+    int rc = trace_async(p, d, n, nullptr, f32, &ticket);
+    if (rc != KR_OK) return rc;
+    int64_t shown = 0;
+    for (;;) {
+        int64_t started = 0;
+        int32_t fin = 1;
+        rc = trace_poll(ticket, &started, &fin);
+        if (rc != KR_OK) break;                       // (the trace itself is still waited for below)
+        if (fn && every > 0) {
+            const int64_t at = started / every * every;
+            if (at > shown) { shown = at; fn(at, n, user); }
+        }
+        if (fin) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+    const int rc2 = trace_wait(ticket, stats);
+    if (stats) stats->rays_total = n;
+    return rc != KR_OK ? rc : rc2;
+}
+}  // namespace
+
+int kr_trace_progress_f64(const kr_params* p, kr_ray_f64* rays, int64_t n, kr_stats* stats, int64_t every, kr_progress_fn fn, void* user)
+{
+    if (!p) { set_error("kr_trace: null params"); return KR_EINVAL; }
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return with_staged_rays(rays, n, sizeof(kr_ray_f64), true, true, stats, [&](void* d) { return trace_with_progress(p, d, n, false, stats, every, fn, user); });
+}
+int kr_trace_progress_f32(const kr_params* p, kr_ray_f32* rays, int64_t n, kr_stats* stats, int64_t every, kr_progress_fn fn, void* user)
+{
+    if (!p) { set_error("kr_trace: null params"); return KR_EINVAL; }
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return with_staged_rays(rays, n, sizeof(kr_ray_f32), true, true, stats, [&](void* d) { return trace_with_progress(p, d, n, true, stats, every, fn, user); });
+}
+int kr_trace_poll(void* ticket, int64_t* rays_started, int32_t* finished)
+{
+    return trace_poll(ticket, rays_started, finished);
 }
 
 // ---- O(N) passes -------------------------------------------------------------------------------------------
@@ -814,7 +870,9 @@ int kr_configure_process(void)
 int kr_shutdown(void)
 {
     if (!g_runtime_touched) return KR_OK;
-    return trace_shutdown();
+    const int rc = trace_shutdown();       // (drains every device this library has used)
+    source_tables_shutdown();
+    return rc;
 }
 
 }  // extern "C"

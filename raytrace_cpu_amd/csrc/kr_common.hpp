@@ -33,8 +33,11 @@ int trace_dev(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, k
 int trace_async(const kr_params* p, void* d_rays, int64_t n, hipStream_t stream, bool f32, void** ticket);
 int trace_batch_async(int count, const kr_params* const* p, void* const* d_rays, const int64_t* n, void* const* streams, void** tickets);
 int trace_wait(void* ticket, kr_stats* stats);
+int trace_poll(void* ticket, int64_t* rays_started, int32_t* finished);
 void trace_release(void* ticket);
 void side_stream_forget(hipStream_t user);
 int trace_shutdown();
+void source_tables_shutdown();
+void angle_values(int kind, double x0, double dx, int n, double* sincos_pairs);     // kind 0: x = cos(alpha); 1: x = beta
 
 }  // namespace kr

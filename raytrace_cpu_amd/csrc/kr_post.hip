@@ -12,7 +12,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "kr_common.hpp"
@@ -102,17 +106,17 @@ __global__ void __launch_bounds__(kBlock) calculate_momentum_kernel(R* __restric
 }
 
 __global__ void __launch_bounds__(kBlock)
-pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, int n_cosalpha, int n_beta, long long first, long long stride)
+pointsource_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, SourceTables tb, int n_cosalpha, int n_beta, long long first, long long stride)
 {
     const long long n_grid = (long long) n_cosalpha * n_beta;
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock)
-        rays[slot] = pointsource_ray(s, n_grid, n_beta, first + slot * stride);
+        rays[slot] = pointsource_ray(s, tb, n_grid, n_beta, first + slot * stride);
 }
 
 // ---- fused prologue of the emissivity pipeline: PointSource ctor + redshift_start() in ONE pass (the record is written once,
 //      with its `emit`); same per-ray functions as the two separate kernels, V == -1 resolved from record 0 as there ----------
 __global__ void __launch_bounds__(kBlock)
-pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, int n_cosalpha, int n_beta, long long first, long long stride,
+pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_pointsource s, SourceTables tb, int n_cosalpha, int n_beta, long long first, long long stride,
                              double V, int reverse, int projradius)
 {
     const long long n_grid = (long long) n_cosalpha * n_beta;
@@ -120,11 +124,11 @@ pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_poin
     if (V == -1) {
         // the reference's loop overwrites V with the orbital velocity at rays[0] of the WHOLE source and keeps it for every ray
         // (raytracer.cpp:389-393): source ray 0, not this shard's first ray
-        const kr_ray_f64 r0 = pointsource_ray(s, n_grid, n_beta, 0);
+        const kr_ray_f64 r0 = pointsource_ray(s, tb, n_grid, n_beta, 0);
         V = keplerian_V<double>(a, r0.r, r0.theta, projradius != 0);
     }
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
-        kr_ray_f64 ray = pointsource_ray(s, n_grid, n_beta, first + slot * stride);
+        kr_ray_f64 ray = pointsource_ray(s, tb, n_grid, n_beta, first + slot * stride);
         ray.emit = emit_value(ray, s.spin, a, V, reverse);
         rays[slot] = ray;
     }
@@ -135,12 +139,13 @@ pointsource_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_poin
 // items of a chunk ride in the kernel arguments (no staging buffer whose lifetime a later call would have to track), blockIdx.y picks the item.
 struct SourceItem {
     kr_pointsource s;
+    SourceTables tb;
     double V;
     kr_ray_f64* rays;
     long long n;
     int n_cosalpha, n_beta;
 };
-constexpr int kSourceChunk = 24;                       // 24 x 160 B of the 4 KB a kernel's arguments may take
+constexpr int kSourceChunk = 19;                       // 19 x 200 B of the 4 KB a kernel's arguments may take
 struct SourceChunk { SourceItem item[kSourceChunk]; };
 
 __global__ void __launch_bounds__(kBlock)
@@ -148,17 +153,18 @@ pointsource_init_emit_multi_kernel(SourceChunk c, int reverse, int projradius)
 {
     const SourceItem& it = c.item[blockIdx.y];
     const kr_pointsource s = it.s;
+    const SourceTables tb = it.tb;
     const long long n = it.n, n_grid = (long long) it.n_cosalpha * it.n_beta;
     const int n_beta = it.n_beta;
     kr_ray_f64* __restrict__ rays = it.rays;
     const double a = reverse ? -1 * s.spin : s.spin;
     double V = it.V;
     if (V == -1) {
-        const kr_ray_f64 r0 = pointsource_ray(s, n_grid, n_beta, 0);
+        const kr_ray_f64 r0 = pointsource_ray(s, tb, n_grid, n_beta, 0);
         V = keplerian_V<double>(a, r0.r, r0.theta, projradius != 0);
     }
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
-        kr_ray_f64 ray = pointsource_ray(s, n_grid, n_beta, slot);
+        kr_ray_f64 ray = pointsource_ray(s, tb, n_grid, n_beta, slot);
         ray.emit = emit_value(ray, s.spin, a, V, reverse);
         rays[slot] = ray;
     }
@@ -539,6 +545,82 @@ int calculate_momentum_dev(double spin, void* d, int64_t n, hipStream_t st, bool
     KR_POST_LAUNCH(calculate_momentum_kernel, spin);
 }
 
+// ---- the PointSource constructor's transcendental values, from the HOST's C library (SourceTables, kr_post_device.hpp) -------------------------
+// One device array of (sin, cos) pairs per distinct (device, kind, first angle / cosine, spacing, count); built on the first call that needs
+// it (a hipMalloc and a blocking 50-KB copy: that one call waits for the copy, no later one does), kept until kr_shutdown.  The hundred sources
+// of a multi-radius driver share one pair of arrays.  A process that keeps inventing new grids fills the cache (kMaxAngleTables): the device is
+// then drained and the arrays are released together, since a kernel in flight may still be reading one.
+namespace {
+struct AngleKey {
+    int dev, kind;           // kind 0: x is cos(alpha) -> (sin, cos) of acos(x);  1: x is beta -> (sin, cos) of x
+    double x0, dx;
+    int n;
+    bool operator<(const AngleKey& o) const { return std::tie(dev, kind, x0, dx, n) < std::tie(o.dev, o.kind, o.x0, o.dx, o.n); }
+};
+std::mutex g_tables_mu;
+std::map<AngleKey, double2*> g_tables;
+constexpr size_t kMaxAngleTables = 256;
+
+}  // namespace
+
+// (sin, cos) pairs of the n angles of one grid axis, with the HOST's C library -- the one the reference's constructor calls.  sincos(), not sin()
+// and cos(): an optimising build of the reference (g++ -O2, the build the oracle is pinned to: 40 calls of sincos in oracle/_ref/libkr_ref.so) merges
+// sin(x) and cos(x) of one argument into ONE sincos(x) call, and glibc's sincos differs from its sin / cos in the last bit of one result on 0.13 % of
+// arguments -- 6 of the 6324 table entries of the BASELINE grid, one of which moved k of one ray in 1e7 by an ulp.
+void angle_values(int kind, double x0, double dx, int n, double* sincos_pairs)
+{
+    for (int i = 0; i < n; i++) {
+        const double x = x0 + i * dx;                               // the reference's own expression (pointsource.cpp:38-39): int -> double, one product, one sum
+        const double ang = kind == 0 ? std::acos(x) : x;            // pointsource.cpp:46
+        ::sincos(ang, &sincos_pairs[2 * i], &sincos_pairs[2 * i + 1]);     // raytracer.cpp:653
+    }
+}
+
+namespace {
+int angle_table(int kind, double x0, double dx, int n, const double2** out)
+{
+    int dev = 0;
+    KR_HIP(hipGetDevice(&dev));
+    const AngleKey key{dev, kind, x0, dx, n};
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) { *out = it->second; return KR_OK; }
+    if (g_tables.size() >= kMaxAngleTables) {
+        KR_HIP(hipDeviceSynchronize());
+        for (auto& kv : g_tables) (void) hipFree(kv.second);
+        g_tables.clear();
+    }
+    std::vector<double2> h((size_t) std::max(n, 1));
+    angle_values(kind, x0, dx, n, reinterpret_cast<double*>(h.data()));
+    double2* d = nullptr;
+    KR_HIP(hipMalloc((void**) &d, h.size() * sizeof(double2)));
+    const hipError_t e = hipMemcpy(d, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void) hipFree(d); return kr::hip_fail(e, "hipMemcpy(angle table)", __FILE__, __LINE__); }
+    g_tables.emplace(key, d);
+    *out = d;
+    return KR_OK;
+}
+
+int source_tables(const kr_pointsource* s, int n_cosalpha, int n_beta, SourceTables* tb)
+{
+    int rc = angle_table(0, s->cosalpha0, s->dcosalpha, n_cosalpha, &tb->alpha_sc);
+    if (rc == KR_OK) rc = angle_table(1, s->beta0, s->dbeta, n_beta, &tb->beta_sc);
+    ::sincos(s->pos[2], &tb->sin_th, &tb->cos_th);                  // raytracer.cpp:631-672 (calculate_constants; see angle_values)
+    tb->tan_th = std::tan(s->pos[2]);
+    return rc;
+}
+}  // namespace
+
+void source_tables_shutdown()
+{
+    std::lock_guard<std::mutex> lk(g_tables_mu);
+    for (auto& kv : g_tables) {
+        if (hipSetDevice(kv.first.dev) == hipSuccess) (void) hipFree(kv.second);
+        else (void) hipGetLastError();
+    }
+    g_tables.clear();
+}
+
 int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st)
 {
     int32_t nc = 0, nb = 0;
@@ -546,7 +628,10 @@ int pointsource_init_dev(const kr_pointsource* s, void* d, int64_t n, int64_t fi
     if (first < 0 || stride < 1) { set_error("kr_pointsource_init: bad first/stride"); return KR_EINVAL; }
     if (first == 0 && stride == 1 && n < total) { set_error("kr_pointsource_init: n smaller than kr_pointsource_count()"); return KR_EINVAL; }
     if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(pointsource_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nc, nb, (long long) first, (long long) stride);
+    SourceTables tb;
+    const int rc = source_tables(s, nc, nb, &tb);
+    if (rc != KR_OK) return rc;
+    hipLaunchKernelGGL(pointsource_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, tb, nc, nb, (long long) first, (long long) stride);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }
@@ -557,7 +642,10 @@ int pointsource_init_emit_dev(const kr_pointsource* s, void* d, int64_t n, int64
     kr_pointsource_count(s, &nc, &nb);
     if (first < 0 || stride < 1) { set_error("kr_pointsource_init_emit: bad first/stride"); return KR_EINVAL; }
     if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(pointsource_init_emit_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nc, nb, (long long) first,
+    SourceTables tb;
+    const int rc = source_tables(s, nc, nb, &tb);
+    if (rc != KR_OK) return rc;
+    hipLaunchKernelGGL(pointsource_init_emit_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, tb, nc, nb, (long long) first,
                        (long long) stride, V, reverse, projradius);
     KR_LAUNCH_CHECK();
     return KR_OK;
@@ -679,7 +767,10 @@ int pointsource_init_emit_batch_dev(int count, const kr_pointsource* s, const do
             if (n[i] <= 0) continue;
             int32_t nc = 0, nb = 0;
             kr_pointsource_count(&s[i], &nc, &nb);
-            c.item[m++] = SourceItem{s[i], V ? V[i] : s[i].V, (kr_ray_f64*) d[i], (long long) n[i], nc, nb};
+            SourceTables tb;
+            const int rc = source_tables(&s[i], nc, nb, &tb);
+            if (rc != KR_OK) return rc;
+            c.item[m++] = SourceItem{s[i], tb, V ? V[i] : s[i].V, (kr_ray_f64*) d[i], (long long) n[i], nc, nb};
             n_max = std::max(n_max, n[i]);
         }
         if (m == 0) continue;

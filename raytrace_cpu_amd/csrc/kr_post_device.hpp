@@ -120,7 +120,19 @@ KR_DEV T range_phi_value(T phi, int steps, T lo, T hi)
 // ---- PointSource ctor: Raytracer ctor (steps=-1, status=0, raytracer.cpp:45-49) + init_pointsource
 //      (pointsource.cpp:30-64) + calculate_constants (raytracer.cpp:625-676).  Fields the reference leaves
 //      indeterminate are zeroed. ------------------------------------------------------------------------
-KR_DEV kr_ray_f64 pointsource_ray(const kr_pointsource& s, long long n_grid, int n_beta, long long ix)
+// The constructor's transcendental values, tabulated ON THE HOST with the C library the reference itself calls: alpha = acos(cos alpha) takes
+// only n_cosalpha distinct values over the whole grid, beta n_beta, and the source position is one point -- so sin(alpha_i), cos(alpha_i), sin(beta_j),
+// cos(beta_j) (two small device arrays: 100 KB at 1e7 rays) and sin / cos / tan of the source's polar angle (three scalars) carry glibc's bits
+// and everything that is left for the device is + - x / sqrt, which is IEEE on both sides: k, h, Q of EVERY device-built ray are the reference
+// constructor's, bit for bit (with the device library's acos 5 % of the rays differed in the last bit of h and Q, and on chaotic rays that is
+// another bin).  kr_post.hip::source_tables builds and caches the arrays per (device, grid).
+struct SourceTables {
+    const double2* alpha_sc;     // [n_cosalpha]  (sin, cos) of acos(cosalpha0 + i dcosalpha)     pointsource.cpp:38,46; raytracer.cpp:653
+    const double2* beta_sc;      // [n_beta]      (sin, cos) of beta0 + j dbeta                   pointsource.cpp:39;    raytracer.cpp:653
+    double sin_th, cos_th, tan_th;   // of pos[2]                                                 raytracer.cpp:631-672
+};
+
+KR_DEV kr_ray_f64 pointsource_ray(const kr_pointsource& s, const SourceTables& tb, long long n_grid, int n_beta, long long ix)
 {
     kr_ray_f64 ray;
         memset(&ray, 0, sizeof(ray));
@@ -130,15 +142,16 @@ KR_DEV kr_ray_f64 pointsource_ray(const kr_pointsource& s, long long n_grid, int
             const double cosalpha = s.cosalpha0 + i * s.dcosalpha;
             const double beta = s.beta0 + j * s.dbeta;
             if (!(cosalpha >= s.cosalphamax || beta >= s.betamax)) {
-                const double alpha = kr_acos(cosalpha);
+                const double2 a_sc = tb.alpha_sc[i], b_sc = tb.beta_sc[j];
+                const double sin_alpha = a_sc.x, cos_alpha = a_sc.y, sin_beta = b_sc.x, cos_beta = b_sc.y;
                 ray.alpha = cosalpha;      // sic: cos(alpha), pointsource.cpp:48
                 ray.beta = beta;
                 ray.t = s.pos[0]; ray.r = s.pos[1]; ray.theta = s.pos[2]; ray.phi = s.pos[3];
                 ray.steps = 0;
 
                 const double spin = s.spin, V = s.V, E = s.E;
-                const double r = ray.r, th = ray.theta;
-                const double st = kr_sin(th), ct = kr_cos(th);
+                const double r = ray.r;
+                const double st = tb.sin_th, ct = tb.cos_th;
                 const double rhosq = r * r + (spin * ct) * (spin * ct);
                 const double delta = r * r - 2 * r + spin * spin;
                 const double sigmasq = (r * r + spin * spin) * (r * r + spin * spin) - spin * spin * delta * st * st;
@@ -154,7 +167,7 @@ KR_DEV kr_ray_f64 pointsource_ray(const kr_pointsource& s, long long n_grid, int
                 const double e22 = -1 / kr_sqrt(rhosq);
                 const double e31 = kr_sqrt(delta / rhosq);
 
-                const double rp0 = E, rp1 = E * kr_sin(alpha) * kr_cos(beta), rp2 = E * kr_sin(alpha) * kr_sin(beta), rp3 = E * kr_cos(alpha);
+                const double rp0 = E, rp1 = E * sin_alpha * cos_beta, rp2 = E * sin_alpha * sin_beta, rp3 = E * cos_alpha;
                 const double tdot = rp0 * et0 + rp1 * e10;
                 const double phidot = rp0 * et3 + rp1 * e13;
                 const double rdot = rp3 * e31;
@@ -165,7 +178,7 @@ KR_DEV kr_ray_f64 pointsource_ray(const kr_pointsource& s, long long n_grid, int
                 h = h - 2 * spin * r * ray.k * st * st;
                 h = h / (r * r + spin * spin * ct * ct - 2 * r);
                 ray.h = h;
-                const double tt = kr_tan(th);
+                const double tt = tb.tan_th;
                 ray.Q = rhosq * rhosq * thetadot * thetadot - (spin * ray.k * ct + h / tt) * (spin * ray.k * ct - h / tt);
                 ray.rdot_sign = (rdot >= 0) ? 1 : -1;
                 ray.thetadot_sign = (thetadot > 0) ? 1 : -1;

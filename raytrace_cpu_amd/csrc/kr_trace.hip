@@ -450,27 +450,32 @@ constexpr int kMaxMultiGrid = 32768;                     // single-wave workgrou
 // It must not share a hardware queue with the caller's stream, or the two launches of a split serialise (seen once a process also
 // holds RCCL's streams: HIP multiplexes streams onto a few queues per priority level).  A different priority level has queues of
 // its own; the main launch it carries is also the one that may wait.
-// One table per device, at most kMaxSideStreams entries each; a process that keeps making streams shares THAT DEVICE's side streams
-// (chosen by a hash of the caller's stream), and kr_stream_destroy / side_stream_forget drops an entry together with its side stream.
+// One table per device: every caller stream that has run a split trace has an entry; at most kMaxSideStreams DISTINCT side streams exist per
+// device -- a process that keeps making streams shares them (chosen by a hash of the caller's stream), each sharer with an entry of its own, so that
+// a side stream is counted by everyone who may launch on it.  kr_stream_destroy / side_stream_forget drops the caller's entry and destroys the side
+// stream when its last user has gone; kr_shutdown destroys the rest.
 constexpr size_t kMaxSideStreams = 16;
-std::map<hipStream_t, hipStream_t> g_side_streams[64];
+std::map<hipStream_t, hipStream_t> g_side_streams[64];      // caller's stream -> side stream
+std::map<hipStream_t, int> g_side_users[64];                // side stream -> number of entries above that point at it
 
 int side_stream_for(int dev, hipStream_t user, hipStream_t* out)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     auto& table = g_side_streams[dev];
+    auto& users = g_side_users[dev];
     auto it = table.find(user);
     if (it == table.end()) {
-        if (table.size() >= kMaxSideStreams) {             // share one of this device's
-            it = table.begin();
-            std::advance(it, (size_t) (((uintptr_t) user) >> 8) % table.size());
-            *out = it->second;
-            return KR_OK;
-        }
-        int least = 0, greatest = 0;
-        KR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         hipStream_t s = nullptr;
-        KR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+        if (users.size() >= kMaxSideStreams) {             // share one of this device's
+            auto pick = users.begin();
+            std::advance(pick, (size_t) (((uintptr_t) user) >> 8) % users.size());
+            s = pick->first;
+        } else {
+            int least = 0, greatest = 0;
+            KR_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            KR_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+        }
+        ++users[s];
         it = table.emplace(user, s).first;
     }
     *out = it->second;
@@ -1115,6 +1120,45 @@ int trace_wait(void* ticket, kr_stats* stats)
     return rc;
 }
 
+// How far the trace behind `ticket` has come: the number of rays its waves have taken off the work queue so far (what the reference's progress
+// counter counts, raytracer.cpp:107-112: a ray is counted when its loop iteration STARTS), and whether the trace has finished.  The queue head lives
+// in device memory; it is read with an 8-byte copy on a stream of the library's own (a DMA transfer: it needs no compute unit, so it completes while
+// the persistent kernels hold every SIMD), a few microseconds per call.  Does not wait for the trace and does not retire the ticket.
+namespace {
+std::mutex g_poll_mu;
+hipStream_t g_poll_stream[64];
+unsigned long long* g_poll_word[64];
+}  // namespace
+
+int trace_poll(void* ticket, int64_t* rays_started, int32_t* finished)
+{
+    if (rays_started) *rays_started = 0;
+    if (finished) *finished = 1;
+    if (!ticket) return KR_OK;                       // the n == 0 call
+    Workspace* ws = (Workspace*) ticket;
+    const hipError_t q = hipEventQuery(ws->done);
+    if (q == hipSuccess) {
+        if (rays_started) *rays_started = ws->n;
+        return KR_OK;
+    }
+    (void) hipGetLastError();
+    if (q != hipErrorNotReady) return kr::hip_fail(q, "hipEventQuery(trace)", __FILE__, __LINE__);
+    if (finished) *finished = 0;
+    int dev = 0;
+    KR_HIP(hipGetDevice(&dev));
+    if (dev != ws->device) { set_error("kr_trace_poll: the ticket belongs to another device than the current one"); return KR_EINVAL; }
+    std::lock_guard<std::mutex> lk(g_poll_mu);
+    if (!g_poll_stream[dev]) {
+        KR_HIP(hipStreamCreateWithFlags(&g_poll_stream[dev], hipStreamNonBlocking));
+        KR_HIP(hipHostMalloc((void**) &g_poll_word[dev], sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    // block 0 = the main launch (or the only one): its head runs over all n slots, also those whose rays belong to the side launch
+    KR_HIP(hipMemcpyAsync(g_poll_word[dev], ws->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, g_poll_stream[dev]));
+    KR_HIP(hipStreamSynchronize(g_poll_stream[dev]));
+    if (rays_started) *rays_started = (int64_t) std::min<unsigned long long>(*g_poll_word[dev], (unsigned long long) ws->n);
+    return KR_OK;
+}
+
 // Gives the ticket back without waiting: the workspace is reused once its trace has finished.
 void trace_release(void* ticket)
 {
@@ -1125,39 +1169,67 @@ void trace_release(void* ticket)
 // end of every split trace, and is synchronised here before it is destroyed).
 void side_stream_forget(hipStream_t user)
 {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void) hipGetLastError(); return; }
+    // (the entry is looked for on every device: the device that is current when a stream is destroyed need not be the one it was used on)
     hipStream_t side = nullptr;
+    int side_dev = -1;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_side_streams[dev].find(user);
-        if (it == g_side_streams[dev].end()) return;
-        side = it->second;
-        g_side_streams[dev].erase(it);
-        // (a workspace still pointing at it belongs to a finished call on the stream being destroyed, or to a sharer -- see below)
-        for (auto& kv : g_side_streams[dev]) if (kv.second == side) return;
+        for (int dev = 0; dev < 64 && side_dev < 0; dev++) {
+            auto it = g_side_streams[dev].find(user);
+            if (it == g_side_streams[dev].end()) continue;
+            hipStream_t s = it->second;
+            g_side_streams[dev].erase(it);
+            auto u = g_side_users[dev].find(s);
+            if (u != g_side_users[dev].end() && --u->second <= 0) {
+                g_side_users[dev].erase(u);
+                side = s;                                    // its last user: nobody can be handed it any more
+                side_dev = dev;
+            } else {
+                return;                                      // other caller streams still launch on it
+            }
+        }
     }
-    (void) hipStreamSynchronize(side);
-    (void) hipStreamDestroy(side);
+    if (!side) return;
+    int keep = 0;
+    const bool have_dev = hipGetDevice(&keep) == hipSuccess;
+    if (hipSetDevice(side_dev) == hipSuccess) {
+        (void) hipStreamSynchronize(side);
+        (void) hipStreamDestroy(side);
+    }
+    if (have_dev) (void) hipSetDevice(keep);
+    (void) hipGetLastError();
 }
 
-// kr_shutdown: waits for the devices this library has used, then gives back every pooled workspace and side stream.  Tickets still
-// outstanding become invalid.
+// kr_shutdown: waits for the devices this library has used, then gives back every pooled workspace and side stream.  Refused (KR_EINVAL, nothing
+// released) while a trace ticket is outstanding: its kr_trace_wait / kr_trace_release would touch a freed workspace.
 int trace_shutdown()
 {
     int keep = 0;
     const bool have_dev = hipGetDevice(&keep) == hipSuccess;
     (void) hipGetLastError();
     std::lock_guard<std::mutex> lk(g_mu);
+    {
+        size_t leased = 0;
+        for (int dev = 0; dev < 64; dev++)
+            for (Workspace* w : g_pool[dev]) leased += w->leased ? 1 : 0;
+        if (leased) {
+            set_error("kr_shutdown: trace tickets are outstanding (kr_trace_wait / kr_trace_release them first)");
+            return KR_EINVAL;
+        }
+    }
     for (int dev = 0; dev < 64; dev++) {
-        if (g_pool[dev].empty() && g_side_streams[dev].empty()) continue;
+        if (g_pool[dev].empty() && g_side_users[dev].empty() && !g_poll_stream[dev]) continue;
         if (hipSetDevice(dev) != hipSuccess) { (void) hipGetLastError(); continue; }
         (void) hipDeviceSynchronize();
         for (Workspace* w : g_pool[dev]) workspace_destroy(w);
         g_pool[dev].clear();
-        std::vector<hipStream_t> seen;
-        for (auto& kv : g_side_streams[dev])
-            if (std::find(seen.begin(), seen.end(), kv.second) == seen.end()) { seen.push_back(kv.second); (void) hipStreamDestroy(kv.second); }
+        {
+            std::lock_guard<std::mutex> pl(g_poll_mu);
+            if (g_poll_stream[dev]) { (void) hipStreamDestroy(g_poll_stream[dev]); g_poll_stream[dev] = nullptr; }
+            if (g_poll_word[dev]) { (void) hipHostFree(g_poll_word[dev]); g_poll_word[dev] = nullptr; }
+        }
+        for (auto& kv : g_side_users[dev]) (void) hipStreamDestroy(kv.first);
+        g_side_users[dev].clear();
         g_side_streams[dev].clear();
     }
     if (have_dev) (void) hipSetDevice(keep);

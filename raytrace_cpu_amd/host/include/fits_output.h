@@ -165,22 +165,32 @@ class FITSOutput {
 public:
     explicit FITSOutput(const char* filename, bool clobber = true) { begin(filename, clobber); }
     explicit FITSOutput(const string& filename, bool clobber = true) { begin(filename.c_str(), clobber); }
-    ~FITSOutput() { close(); }
+    ~FITSOutput() { finish(false); }
     FITSOutput(const FITSOutput&) = delete;
     FITSOutput& operator=(const FITSOutput&) = delete;
 
-    void close()
+    // Throws when any write of the file failed (the background writer records ENOSPC, EIO, ... and they surface here): a program that
+    // calls close() -- imageplane_disc_image.cpp:340 does -- must not go on to report success over a truncated file.  (The destructor
+    // only prints: it cannot throw.)
+    void close() { finish(true); }
+
+private:
+    void finish(bool may_throw)
     {
         if (!open_) return;
         flush_hdu();
         for (int b = 0; b < 2; ++b) wait_for(b);
         for (int b = 0; b < 2; ++b) { free(buf_[b]); buf_[b] = nullptr; cap_[b] = 0; }
-        if (::close(fd_) != 0) io_error_ = errno;
+        if (::close(fd_) != 0 && !io_error_) io_error_ = errno;
         fd_ = -1;
         open_ = false;
-        if (io_error_) cerr << "FITSOutput ERROR : writing the file failed: " << strerror(io_error_) << endl;
+        if (!io_error_) return;
+        const string what = string("writing the file failed: ") + strerror(io_error_);
+        if (may_throw) throw FITSOutputException(what);
+        cerr << "FITSOutput ERROR : " << what << endl;
     }
 
+public:
     // an empty primary array, so that keywords can be attached to the file as a whole
     void create_primary()
     {

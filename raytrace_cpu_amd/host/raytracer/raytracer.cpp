@@ -8,12 +8,17 @@
 
 #include "raytracer.h"
 
+#include <sys/ioctl.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <map>
@@ -50,8 +55,49 @@ inline void check(int rc, const char* what)
     if (rc != KR_OK) fail(what, rc);
 }
 
-int trace_call(const kr_params* p, Ray<double>* rays, long n) { return kr_trace_f64(p, reinterpret_cast<kr_ray_f64*>(rays), n, nullptr); }
-int trace_call(const kr_params* p, Ray<float>* rays, long n) { return kr_trace_f32(p, reinterpret_cast<kr_ray_f32*>(rays), n, nullptr); }
+// The line run_raytrace draws while it works (reference src/include/progress_bar.h:25-75 as used by raytracer.cpp:84-85, :107-115, :126: label "Ray",
+// the count right-aligned to the width of the total, a bar as wide as the terminal allows; show_progress < 0: one plain line per report).  The count
+// is the number of rays whose integration has STARTED, as in the reference; here it is read from the trace's work queue while the kernels run.
+class ProgressLine {
+public:
+    ProgressLine(long end, bool draw_bar) : end_(end), draw_bar_(draw_bar)
+    {
+        for (long e = end; e; e /= 10) ++digits_;
+        struct winsize w;
+        const int cols = ioctl(STDOUT_FILENO, TIOCGWINSZ, &w) == 0 ? w.ws_col : 0;       // (not a terminal: no bar cells)
+        length_ = cols - 3 - 2 * digits_ - 5;
+    }
+    void show(long at)
+    {
+        std::ostringstream line;
+        if (draw_bar_) {
+            line << "\033[?25l" << "\r" << "Ray" << ' ' << std::setw(digits_) << at << '/' << end_ << " [";
+            for (int cell = 1; cell <= length_; cell++) line << (((float) cell / length_) <= ((float) at / end_) ? "\u2588" : "-");
+            line << ']' << "\033[?25h";
+        } else {
+            line << "Ray" << ' ' << std::setw(digits_) << at << '/' << end_ << std::endl;
+        }
+        std::cout << line.str() << std::flush;
+    }
+    void done() { std::cout << std::endl; }
+
+private:
+    long end_;
+    int length_ = 0, digits_ = 0;
+    bool draw_bar_;
+};
+void progress_cb(int64_t at, int64_t, void* user) { static_cast<ProgressLine*>(user)->show((long) at); }
+
+int trace_call(const kr_params* p, Ray<double>* rays, long n, long every, ProgressLine* line)
+{
+    if (every > 0 && line) return kr_trace_progress_f64(p, reinterpret_cast<kr_ray_f64*>(rays), n, nullptr, every, progress_cb, line);
+    return kr_trace_f64(p, reinterpret_cast<kr_ray_f64*>(rays), n, nullptr);
+}
+int trace_call(const kr_params* p, Ray<float>* rays, long n, long every, ProgressLine* line)
+{
+    if (every > 0 && line) return kr_trace_progress_f32(p, reinterpret_cast<kr_ray_f32*>(rays), n, nullptr, every, progress_cb, line);
+    return kr_trace_f32(p, reinterpret_cast<kr_ray_f32*>(rays), n, nullptr);
+}
 
 template <typename T>
 bool builtin_destination(const RayDestination<T>* dest, int& kind, double sp[4], bool& default_velocity)
@@ -214,11 +260,20 @@ void Raytracer<T>::fill_params(void* out, Integrator method, T r_max, int stepli
 }
 
 template <typename T>
-void Raytracer<T>::trace(const void* params, Ray<T>* first, long n)
+void Raytracer<T>::trace(const void* params, Ray<T>* first, long n, int show_progress)
 {
     if (n > 1) mark("run_raytrace: begin");
     g_warm_up.ready(rays, n > 1);
-    check(trace_call(static_cast<const kr_params*>(params), first, n), "kr_trace");
+    if (n > 1) {
+        // what run_raytrace writes on stdout (raytracer.cpp:76-85, :126): the integrator's name, the progress line, a newline
+        static const char* names[] = {"Running raytracer...", "Running raytracer (RK4)...", "Running raytracer (RK45/DOPRI5)..."};
+        std::cout << names[static_cast<const kr_params*>(params)->integrator] << std::endl;
+        ProgressLine line(n, show_progress > 0);
+        check(trace_call(static_cast<const kr_params*>(params), first, n, std::abs((long) show_progress), &line), "kr_trace");
+        line.done();
+    } else {
+        check(trace_call(static_cast<const kr_params*>(params), first, n, 0, nullptr), "kr_trace");
+    }
     if (n > 1) mark("run_raytrace: end");
 }
 
@@ -226,19 +281,19 @@ template <typename T>
 void Raytracer<T>::run_raytrace(Integrator method, T theta_max, T r_max, int show_progress, TextOutput* outfile, int write_step,
                                 T write_rmax, T write_rmin, bool write_cartesian, int steplim)
 {
-    (void) show_progress; (void) write_step; (void) write_rmax; (void) write_rmin; (void) write_cartesian;
+    (void) write_step; (void) write_rmax; (void) write_rmin; (void) write_cartesian;
     no_outfile(outfile);
     kr_params p;
     fill_params(&p, method, r_max, steplim);
     p.theta_max = theta_max;
-    trace(&p, rays, nRays);
+    trace(&p, rays, nRays, show_progress);
 }
 
 template <typename T>
 void Raytracer<T>::run_raytrace(RayDestination<T>* dest, Integrator method, T r_max, int show_progress, TextOutput* outfile,
                                 int write_step, T write_rmax, T write_rmin, bool write_cartesian, int steplim)
 {
-    (void) show_progress; (void) write_step; (void) write_rmax; (void) write_rmin; (void) write_cartesian;
+    (void) write_step; (void) write_rmax; (void) write_rmin; (void) write_cartesian;
     no_outfile(outfile);
     if (method == Integrator::Euler)   // assert in the reference, raytracer.cpp:983
         throw std::invalid_argument("Integrator::Euler does not support RayDestination stopping conditions");
@@ -249,7 +304,7 @@ void Raytracer<T>::run_raytrace(RayDestination<T>* dest, Integrator method, T r_
         throw std::runtime_error("Raytracer::run_raytrace: only FlatDiscDestination, DiscWithISCODestination and FlatPlaneDestination "
                                  "can be evaluated by the HIP kernel; a user-defined RayDestination would need per-step host callbacks");
     p.flags = arithmetic_flags(p.integrator, true);
-    trace(&p, rays, nRays);
+    trace(&p, rays, nRays, show_progress);
 }
 
 // ---- single-ray forms --------------------------------------------------------------------------------------
@@ -270,7 +325,7 @@ void Raytracer<T>::run_raytrace(RayDestination<T>* dest, Integrator method, T r_
         rays[ray].status |= KR_STATUS_STEPLIM;                                                          \
     } else {                                                                                            \
         rays[ray].steps = 0;                                                                            \
-        trace(&p, &rays[ray], 1);                                                                       \
+        trace(&p, &rays[ray], 1, 0);                                                                     \
         taken = std::abs(rays[ray].steps);                                                              \
     }                                                                                                   \
     rays[ray].steps = before + taken;                                                                   \

@@ -12,7 +12,8 @@
 //   * a RayDestination subclass other than the three built-ins in run_raytrace()       -> std::runtime_error
 //   * an RK45 ray whose error norm is NaN ends with RAY_STATUS_NAN instead of hanging the process
 //   * `new Ray<T>[n]` is value-initialised (the reference leaves most fields indeterminate)
-//   * show_progress is accepted and ignored (a GPU launch has no per-ray progress)
+//   * show_progress reports the rays the kernels have taken off their work queue, polled every 20 ms (the reference: one report per
+//     `show_progress` rays from the OpenMP loop): the same line, fewer updates
 #ifndef RAYTRACER_H_
 #define RAYTRACER_H_
 
@@ -192,7 +193,7 @@ private:
     T rk45_tol;
 
     void fill_params(void* kr_params_out, Integrator method, T r_max, int steplim) const;   // -> kr_params of the C ABI
-    void trace(const void* kr_params_in, Ray<T>* first, long n);                            // kr_trace_f64 / kr_trace_f32
+    void trace(const void* kr_params_in, Ray<T>* first, long n, int show_progress);         // kr_trace_f64 / kr_trace_f32 (kr_trace_progress_* while reporting)
 };
 
 #endif /* RAYTRACER_H_ */

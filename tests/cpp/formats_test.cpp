@@ -7,9 +7,13 @@
 //   formats_test cards <spec.txt> <out.fits>             replay a list of FITSOutput calls (P | I nx ny | E name | C text |
 //                                                        K{i,l,d,s,b} key|comment|value), images filled with zeros
 //   formats_test par  <parfile> [--key=value ...]        print what ParameterFile / ParameterArgs parse
+//   formats_test fullimage <file> <limit>                one 512 x 512 image under RLIMIT_FSIZE = limit bytes (0: none); exit code 3 when the
+//                                                        writer reports an I/O error
 //   formats_test area <spin> <r0> <r1>                   integrate_disc_area(r0, r1, spin), 17 digits
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
+#include <sys/resource.h>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -156,6 +160,27 @@ int main(int argc, char** argv)
     if (mode == "fits" && argc == 6) return redo_fits(argv[2], argv[3], atol(argv[4]), argv[5]);
     if (mode == "cards" && argc == 4) return replay_cards(argv[2], argv[3]);
     if (mode == "par" && argc >= 3) return show_par(argc, argv);
+    if (mode == "fullimage" && argc == 4) {
+        // a 512 x 512 image (2 MB) into <file> under a file-size limit of <limit> bytes (0: none): writes beyond it fail (EFBIG) and close() has to say so
+        if (atol(argv[3]) > 0) {
+            signal(SIGXFSZ, SIG_IGN);
+            struct rlimit lim = {(rlim_t) atol(argv[3]), (rlim_t) atol(argv[3])};
+            setrlimit(RLIMIT_FSIZE, &lim);
+        }
+        try {
+            FITSOutput<double> fits(argv[2]);
+            fits.create_primary();
+            vector<double> img(512 * 512, 1.0);
+            vector<double*> rows(512);
+            for (int i = 0; i < 512; ++i) rows[i] = &img[(size_t) i * 512];
+            fits.write_image(rows.data(), 512, 512);
+            fits.close();
+        } catch (const FITSOutputException& e) {
+            cerr << e.what() << endl;
+            return 3;
+        }
+        return 0;
+    }
     if (mode == "area" && argc == 5) {
         printf("%.17g\n", integrate_disc_area(atof(argv[3]), atof(argv[4]), atof(argv[2])));
         return 0;

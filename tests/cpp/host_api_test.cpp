@@ -3,6 +3,7 @@
 // Exit code 0 = every check passed; each failed check prints a line.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <vector>
 
@@ -45,6 +46,18 @@ int main(int argc, char** argv)
             }
         }
         CHECK(live > 100 && capped > 50, "too few rays: live %d capped %d", live, capped);
+        std::printf(failures ? "FAIL\n" : "PASS\n");
+        return failures ? 1 : 0;
+    }
+
+    if (argc > 1 && !std::strcmp(argv[1], "progress")) {
+        // run_raytrace(show_progress = -250000) on 2e6 rays: plain report lines "Ray <done>/<total>" (negative: no bar), the integrator's banner first
+        const double d = 1.99 / (std::sqrt(2.0e6) - 1.0);
+        PointSource<double> a(pos, 0.0, spin, TOL, d, d * M_PI / 0.995, -0.995, 0.995, -M_PI, M_PI);
+        a.run_raytrace(Integrator::RK4, M_PI_2, 1000.0, -250000);
+        int traced = 0;
+        for (int i = 0; i < a.get_count(); i++) traced += a.rays[i].steps > 0;
+        CHECK(traced > 1900000, "traced %d", traced);
         std::printf(failures ? "FAIL\n" : "PASS\n");
         return failures ? 1 : 0;
     }

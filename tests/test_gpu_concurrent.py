@@ -325,3 +325,92 @@ def test_many_streams_share_side_streams_and_shutdown_releases_them(krlib):
     finally:
         buf.free()
         big.free()
+
+
+def test_shared_side_streams_outlive_one_of_their_users_and_shutdown_waits_for_tickets(krlib):
+    """Host-state rules of the split trace (kr_trace.hip): (i) beyond 16 caller streams per device the side streams are shared, every sharer is
+    counted, and destroying one caller stream must leave the side stream alive for the others -- 20 streams trace, the first 10 are destroyed,
+    the other 10 trace again, same bits; (ii) kr_shutdown is refused while a ticket is outstanding and works afterwards, after which the
+    library starts from scratch (new workspaces, new side streams, new PointSource tables)."""
+    lib = krlib
+    spec = bench.make_spec(capi, bench.grid_spacing_for(3.0e5))
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, bench.R_MAX, capi.FLAG_HYBRID
+    b = DeviceRays(lib, spec)
+    streams = []
+    try:
+        b.init()
+        api.trace_dev(p, b.d.value, b.n)
+        want = b.fetch()
+        for _ in range(20):
+            s = C.c_void_p()
+            capi.check(lib, lib.kr_stream_create(C.byref(s)), "stream")
+            streams.append(s)
+        for s in streams:                      # every stream runs a split trace: 16 side streams, 4 sharers
+            b.init(s.value)
+            api.trace_dev(p, b.d.value, b.n, stream=s.value)
+        for s in streams[:10]:
+            capi.check(lib, lib.kr_stream_destroy(s), "destroy")
+        streams = streams[10:]
+        for s in streams:
+            b.init(s.value)
+            api.trace_dev(p, b.d.value, b.n, stream=s.value)
+            assert same_bits(b.fetch(), want)
+        # (ii)
+        b.init()
+        t = api.trace_async(p, b.d.value, b.n)
+        assert lib.kr_shutdown() == capi.KR_EINVAL and b"outstanding" in lib.kr_last_error()
+        api.trace_wait(t)
+        assert same_bits(b.fetch(), want)
+        for s in streams:
+            capi.check(lib, lib.kr_stream_destroy(s), "destroy")
+        streams = []
+        capi.check(lib, lib.kr_shutdown(), "shutdown")
+        b.init()
+        api.trace_dev(p, b.d.value, b.n)
+        assert same_bits(b.fetch(), want)
+    finally:
+        for s in streams:
+            lib.kr_stream_destroy(s)
+        b.free()
+
+
+def test_progress_of_a_trace_in_flight(krlib):
+    """run_raytrace's show_progress (raytracer.cpp:84-85, :107-115) on the HIP path: kr_trace_poll reads the work queue's head while the persistent
+    kernels run -- monotone, between 0 and n, n once the trace has finished, and it must actually MOVE during a 0.15-s launch (a read that only
+    completes when the kernels have drained would be no progress report at all); kr_trace_progress_f64 reports multiples of `every`."""
+    import time
+    lib = krlib
+    spec = bench.make_spec(capi, bench.grid_spacing_for(1.0e7))
+    p = capi.default_params(bench.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, bench.R_MAX, 0            # all-strict: ~0.16 s
+    b = DeviceRays(lib, spec)
+    try:
+        b.init()
+        capi.check(lib, lib.kr_synchronize(None), "sync")
+        t = api.trace_async(p, b.d.value, b.n)
+        seen = []
+        started, fin = C.c_int64(), C.c_int32()
+        while True:
+            capi.check(lib, lib.kr_trace_poll(t, C.byref(started), C.byref(fin)), "poll")
+            seen.append(started.value)
+            if fin.value:
+                break
+            time.sleep(0.005)
+        st = api.trace_wait(t)
+        assert seen[-1] == b.n == st["rays_total"]
+        assert all(x <= y for x, y in zip(seen, seen[1:])) and all(0 <= x <= b.n for x in seen)
+        assert any(0 < x < b.n for x in seen), seen[:5] + seen[-5:]
+    finally:
+        b.free()
+    # the host-pointer form with a callback, as the class mirror uses it
+    spec = bench.make_spec(capi, bench.grid_spacing_for(2.0e6))
+    rays = api.pointsource_init(spec)
+    marks = []
+    cb = capi.PROGRESS_FN(lambda at, total, user: marks.append((at, total)))
+    st = capi.Stats()
+    capi.check(lib, lib.kr_trace_progress_f64(C.byref(p), rays.ctypes.data_as(C.c_void_p), len(rays), C.byref(st), 250000, cb, None), "trace with progress")
+    assert st.rays_traced > 1.9e6 and marks, marks
+    assert all(at % 250000 == 0 and 0 < at <= len(rays) and total == len(rays) for at, total in marks)
+    assert all(x[0] < y[0] for x, y in zip(marks, marks[1:]))
+    assert (rays["steps"][rays["steps"] != -1] != 0).all()

@@ -113,6 +113,86 @@ def test_full_size_properties(krlib, flags):
         lib.kr_free(d_rays)
 
 
+def test_timed_pipeline_equals_the_cpu_reference_at_full_size(krlib):
+    """BASELINE configs[1] end to end, the way bench.py TIMES it -- device PointSource constructor + redshift_start (fused), hybrid trace, fused
+    range_phi + redshift + histogram, nothing leaving HBM but the 501 histogram words -- against the CPU on the same 3162^2 grid: the reference's
+    own PointSource constructor and run_raytrace (oracle/_ref; the oracle port where it was not built) + the oracle's O(N) passes and reducer.
+      * every device-built record carries the reference constructor's bits (host-tabulated acos / sin / cos / tan, kr_post_device.hpp::SourceTables);
+      * the launch takes exactly the CPU's number of RK4 steps;
+      * every bin's count is the CPU's; sums within the north-star 1e-6 (measured ~1e-11)."""
+    import os
+    lib = krlib
+    spec = _spec(1.99 / (math.sqrt(1e7) - 1.0))
+    n = lib.kr_pointsource_count(C.byref(spec), None, None)
+    p = capi.default_params(gc.SPIN)
+    p.integrator, p.r_max, p.flags = capi.RK4, 1000.0, capi.FLAG_HYBRID
+    # CPU leg (reference where built): constructor -> redshift_start -> run_raytrace -> range_phi -> redshift -> reducer
+    threads = min(64, len(os.sched_getaffinity(0)))
+    if ol.ref() is not None:
+        src = ol.RefSource(spec)
+        src.lib.ref_redshift_start(src.h, 0.0, 0, 0)
+        init = src.snapshot()
+        try:
+            C.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+        except OSError:
+            pass
+        src.run(p)
+        cpu = src.snapshot()
+        src.close()
+    else:
+        init = ol.oracle_pointsource(spec)
+        ol.oracle().kro_redshift_start_f64(gc.SPIN, 0.0, 0, 0, ol.ptr(init), len(init))
+        cpu, _ = ol.oracle_trace(p, init, nthreads=threads)
+    assert len(init) == n
+    live = cpu["steps"] != -1
+    cpu_steps = int(np.abs(cpu["steps"][live].astype(np.int64)).sum())
+    o = ol.oracle()
+    o.kro_range_phi_f64(-math.pi, math.pi, ol.ptr(cpu), len(cpu))
+    o.kro_redshift_f64(gc.SPIN, -1.0, 0, 0, 0, ol.ptr(cpu), len(cpu))
+    bins = gc.emis_bins(spec, nr=100)
+    nr = bins.nr
+    cnt = np.zeros(nr, dtype=np.int64)
+    flux, emis, sg, stt = (np.zeros(nr) for _ in range(4))
+    dc = C.c_int64()
+    o.kro_reduce_emissivity_f64(C.byref(bins), ol.ptr(cpu), len(cpu), ol.ptr(cnt), ol.ptr(flux), ol.ptr(emis), ol.ptr(sg), ol.ptr(stt), C.byref(dc))
+    # device leg: the fused pipeline
+    d_rays, d_hist = vp(), vp()
+    words = 5 * nr + 1
+    capi.check(lib, lib.kr_malloc(C.byref(d_rays), n * 144), "malloc")
+    capi.check(lib, lib.kr_malloc(C.byref(d_hist), words * 8), "malloc")
+    try:
+        capi.check(lib, lib.kr_pointsource_init_emit_dev_f64(C.byref(spec), 0, 1, 0.0, 0, 0, d_rays, n, None), "init_emit")
+        dev_init = np.zeros(n, dtype=capi.RAY_F64)
+        capi.check(lib, lib.kr_memcpy_d2h(dev_init.ctypes.data_as(vp), d_rays, n * 144), "d2h")
+        assert np.array_equal(dev_init["steps"], init["steps"])
+        fresh = init["steps"] == 0
+        for f in ("t", "r", "theta", "phi", "k", "h", "Q", "emit", "alpha", "beta"):
+            assert np.array_equal(dev_init[f][fresh].view(np.int64), init[f][fresh].view(np.int64)), f
+        for f in ("rdot_sign", "thetadot_sign", "status"):
+            assert np.array_equal(dev_init[f][fresh], init[f][fresh]), f
+        del dev_init
+        st = capi.Stats()
+        capi.check(lib, lib.kr_trace_dev_f64(C.byref(p), d_rays, n, None, C.byref(st)), "trace")
+        capi.check(lib, lib.kr_memset(d_hist, 0, words * 8), "memset")
+        capi.check(lib, lib.kr_post_emissivity_dev_f64(gc.SPIN, -1.0, 0, 0, 0, -math.pi, math.pi, C.byref(bins), d_rays, n, d_hist, None), "post")
+        h = np.zeros(words)
+        capi.check(lib, lib.kr_memcpy_d2h(h.ctypes.data_as(vp), d_hist, words * 8), "d2h")
+    finally:
+        lib.kr_free(d_rays)
+        lib.kr_free(d_hist)
+    assert st.rays_traced == int(live.sum())
+    assert st.steps_total == cpu_steps, (st.steps_total, cpu_steps)
+    assert np.array_equal(np.rint(h[:nr]).astype(np.int64), cnt)
+    assert int(round(h[5 * nr])) == dc.value > 5e6
+    worst = 0.0
+    for k, w in enumerate((flux, emis, sg, stt)):
+        m = cnt > 0
+        worst = max(worst, float(np.max(np.abs(h[(k + 1) * nr:(k + 2) * nr][m] - w[m]) / np.abs(w[m]))))
+    parity.record_margin("test_timed_pipeline_equals_the_cpu_reference_at_full_size", "ps1e7-rk4-hybrid",
+                         {"n_traced": int(live.sum()), "n_bad": 0, "frac_bad": 0.0, "worst_ok": worst}, bins_count_mismatch=0, rk_steps=int(st.steps_total))
+    assert worst <= 1e-6, worst
+
+
 def test_rk45_creep_mode_at_scale(krlib):
     """1e6 rays of the BASELINE source under RK45, strict arithmetic: carrying the ~2000 creeping captured rays to the step limit
     from k1 alone (default) against iterating all of their 1e5 steps (KR_FLAG_RK45_ITERATE_ALL) -- every ray's r, theta, status,

@@ -22,3 +22,15 @@ def test_krtrace_steplim_environment_knob():
     d = os.path.join(gc.ROOT, "tests", "cpp")
     r = subprocess.run([os.path.join(d, "host_api_test"), "steplim-env"], capture_output=True, text=True, timeout=600, env=dict(os.environ, KRTRACE_STEPLIM="40"))
     assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_show_progress_reports_from_the_running_kernels():
+    """run_raytrace(show_progress) through the class mirror: the integrator's banner, then report lines whose counts are multiples of |show_progress|,
+    increasing, and the newline of ProgressBar::done() (raytracer.cpp:76-85, :107-115, :126)."""
+    import re
+    d = os.path.join(gc.ROOT, "tests", "cpp")
+    r = subprocess.run([os.path.join(d, "host_api_test"), "progress"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("PASS"), r.stdout[-3000:] + r.stderr[-1000:]
+    assert "Running raytracer (RK4)..." in r.stdout
+    marks = [(int(a), int(b)) for a, b in re.findall(r"^Ray\s+(\d+)/(\d+)$", r.stdout, flags=re.M)]
+    assert marks and all(a % 250000 == 0 and 0 < a <= b for a, b in marks) and all(x[0] < y[0] for x, y in zip(marks, marks[1:])), r.stdout[-2000:]

@@ -185,6 +185,13 @@ def test_source_init_and_redshift_start(krlib, case_name):
     same = {f: float((rays[f][live].view(np.int64) == want[f][live].view(np.int64)).mean()) for f in ("k", "h", "Q", "emit", "theta", "phi")}
     parity.record_margin("test_source_init_and_redshift_start", case_name, {"n_traced": int(live.sum()), "n_bad": 0, "frac_bad": 0.0, "worst_ok": None},
                          **{f"frac_bit_identical_{f}": v for f, v in same.items()})
+    if not gc.is_imageplane(case):
+        # PointSource: the constructor's sin / cos / acos / tan values come from host-built tables (glibc, as in the reference) and the rest is
+        # IEEE + - x / sqrt on both sides -- every field of every device-built record carries the reference's bits (pointsource.cpp:30-64,
+        # raytracer.cpp:625-676); `emit` goes through the device's correctly rounded sin / cos of the ONE source position
+        for f in ("t", "r", "theta", "phi", "k", "h", "Q", "alpha", "beta"):
+            assert (rays[f][live].view(np.int64) == want[f][live].view(np.int64)).all(), f
+        assert same["emit"] == 1.0, same
 
 
 def test_redshift_variants_vs_oracle(krlib):

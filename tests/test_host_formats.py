@@ -142,3 +142,13 @@ def test_non_ascii_header_text_becomes_blanks(exe, tmp_path):
     subprocess.run([exe, "cards", str(spec), str(out)], check=True, stdout=subprocess.DEVNULL)
     cards = fits_lite.header_cards(str(out))[0]
     assert "COMMENT mapping     source sphere".ljust(80) in cards
+
+
+def test_fits_writer_reports_a_failed_write(exe, tmp_path):
+    """The threaded writer records I/O errors of its background pwrite slices; close() must surface them (a program that goes on to print
+    "Done" over a truncated file is worse than one that stops).  The 2-MB image is written under a 1-MB file-size limit (EFBIG)."""
+    r = subprocess.run([exe, "fullimage", str(tmp_path / "cut.fits"), str(1 << 20)], capture_output=True, text=True)
+    assert r.returncode == 3, (r.returncode, r.stderr[-300:])
+    assert "writing the file failed" in r.stderr
+    ok = subprocess.run([exe, "fullimage", str(tmp_path / "ok.fits"), "0"], capture_output=True, text=True)
+    assert ok.returncode == 0 and os.path.getsize(tmp_path / "ok.fits") % 2880 == 0
