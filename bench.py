@@ -822,6 +822,9 @@ def main():
                        "sharding": wl.sharding},
             "rk_steps_per_sec": steps_all * args.steps / elapsed,
             "rk_steps_per_launch": int(steps_total), "mean_steps_per_ray": steps_total / max(traced, 1),
+            # the strict side launch's share of the work (split traces): with per-kernel profiler counters, instructions per step of EACH launch
+            "launch_split": {"rays_strict_side": int(stats_last.get("rays_strict_side", 0)), "steps_strict_side": int(stats_last.get("steps_strict_side", 0)),
+                             "work_units_strict_side": int(stats_last.get("rk45_evaluated_strict_side", 0) if args.integrator == "rk45" else stats_last.get("steps_strict_side", 0))},
             "roofline": {"bound": "valu_fp64", "kernel": "kr::trace_kernel<double>", "achieved": achieved_tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / FP64_VECTOR_PEAK_TFLOPS,
                          "flop_per_step": FLOP_PER_STEP[args.integrator], "work_units_per_launch": int(units), "avg_kernel_ms": avg_kernel_ms,

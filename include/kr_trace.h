@@ -157,6 +157,9 @@ typedef struct kr_stats {
                                        carries it lasts at least this many wave steps whatever else the GPU does (DESIGN.md "Known limit") */
     int64_t longest_ray_steps_strict_side; /* the same over the rays of the strict side launch of a split trace (0 otherwise):
                                        strict_side_ms / this = that launch's time per step on a wave of its own */
+    int64_t steps_strict_side;      /* steps_total of the strict side launch alone (split traces; 0 otherwise): with the profiler's per-kernel counters,
+                                       instructions per step of EACH of the two launches */
+    int64_t rk45_evaluated_strict_side; /* RK45: trial steps the strict side launch evaluated in full (its attempts minus replayed / extrapolated steps) */
 } kr_stats;
 
 /* PointSource<T> ctor arguments (pointsource.h:24, pointsource.cpp:11-64) */

@@ -39,7 +39,8 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("rays_total", "rays_traced", "steps_total", "rk45_attempts", "rk45_rejects")] + \
                [(n, C.c_double) for n in ("kernel_ms", "h2d_ms", "d2h_ms")] + [("rays_strict_side", C.c_int64), ("rk45_stationary_steps", C.c_int64), ("rk45_extrapolated_steps", C.c_int64)] + \
-               [("strict_side_ms", C.c_double), ("main_ms", C.c_double), ("longest_ray_steps", C.c_int64), ("longest_ray_steps_strict_side", C.c_int64)]
+               [("strict_side_ms", C.c_double), ("main_ms", C.c_double), ("longest_ray_steps", C.c_int64), ("longest_ray_steps_strict_side", C.c_int64),
+                ("steps_strict_side", C.c_int64), ("rk45_evaluated_strict_side", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -356,6 +356,7 @@ int kr_trace_wait_many(int32_t count, void* const* tickets, kr_stats* per_ticket
             total->rays_total += st.rays_total; total->rays_traced += st.rays_traced; total->steps_total += st.steps_total;
             total->rk45_attempts += st.rk45_attempts; total->rk45_rejects += st.rk45_rejects; total->rays_strict_side += st.rays_strict_side;
             total->rk45_stationary_steps += st.rk45_stationary_steps; total->rk45_extrapolated_steps += st.rk45_extrapolated_steps;
+            total->steps_strict_side += st.steps_strict_side; total->rk45_evaluated_strict_side += st.rk45_evaluated_strict_side;
             total->kernel_ms = std::max(total->kernel_ms, st.kernel_ms);
             total->strict_side_ms = std::max(total->strict_side_ms, st.strict_side_ms);
             total->main_ms = std::max(total->main_ms, st.main_ms);

@@ -1100,6 +1100,8 @@ int trace_wait(void* ticket, kr_stats* stats)
         stats->rk45_extrapolated_steps = (int64_t) h[6];
         stats->longest_ray_steps = (int64_t) h[7];
         stats->longest_ray_steps_strict_side = ws->split ? (int64_t) h2[kCounters + 7] : 0;
+        stats->steps_strict_side = ws->split ? (int64_t) h2[kCounters + 2] : 0;
+        stats->rk45_evaluated_strict_side = ws->split ? (int64_t) (h2[kCounters + 3] - h2[kCounters + 5] - h2[kCounters + 6]) : 0;
         float ms = 0;
         KR_HIP(hipEventElapsedTime(&ms, ws->ev0, ws->ev1));
         stats->kernel_ms = ms;

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layouts_match_header(lib):
     assert capi.RAY_F64.itemsize == 144 and capi.RAY_F32.itemsize == 84      # Ray<double>, Ray<float>
     assert capi.RAY_F64.fields["steps"][1] == 104 and capi.RAY_F64.fields["alpha"][1] == 128
-    assert C.sizeof(capi.Params) == 128 and C.sizeof(capi.Stats) == 120
+    assert C.sizeof(capi.Params) == 128 and C.sizeof(capi.Stats) == 136
     assert C.sizeof(capi.PointSourceSpec) == 112 and C.sizeof(capi.ImagePlaneSpec) == 88
     assert C.sizeof(capi.EmisBins) == 56 and C.sizeof(capi.ImageBins) == 104 and C.sizeof(capi.ReturnBins) == 56
     p = capi.Params()
