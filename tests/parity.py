@@ -96,13 +96,25 @@ def compare_rays(got, want, rtol=RAY_RTOL, check_redshift=False, steps_slack=2):
             "frac_terminal_status_differs": float(term_bad.sum()) / max(n_live, 1), "bad_index": np.flatnonzero(bad)}
 
 
-def compare_bins(got, want, rtol=BIN_RTOL, slack=BIN_COUNT_SLACK):
-    """got/want: dicts with count, flux, emis, sum_redshift, sum_time.  Returns list of problems (empty = pass)."""
+_BIN_EXCLUSIONS = []
+
+
+def compare_bins(got, want, rtol=BIN_RTOL, slack=BIN_COUNT_SLACK, max_excluded=None, label=""):
+    """got/want: dicts with count, flux, emis, sum_redshift, sum_time.  Returns list of problems (empty = pass).
+    A bin whose count differs by one (a chaotic ray landed next door) cannot be held to 1e-6 in its sums and is left out of the sum check -- but how
+    many bins that may be is bounded: max_excluded (default: 2 % of the non-empty bins, at least 2: one moved ray changes two bins), and the number
+    is recorded with the round's margins (gpurun_out/parity_margins.json)."""
     problems = []
     dc = np.abs(got["count"].astype(np.int64) - want["count"].astype(np.int64))
     if (dc > slack).any():
         problems.append(("count", int(dc.max()), int(np.argmax(dc))))
     same = dc == 0
+    nonempty = int((want["count"] > 0).sum())
+    excluded = int((~same & (want["count"] > 0)).sum())
+    bound = max(2, nonempty // 50) if max_excluded is None else max_excluded
+    _BIN_EXCLUSIONS.append({"label": label, "bins_nonempty": nonempty, "bins_excluded_from_the_sum_check": excluded, "allowed": bound})
+    if excluded > bound:
+        problems.append(("excluded_bins", excluded, bound))
     for k in ("flux", "emis", "sum_redshift", "sum_time"):
         g, w = got[k][same], want[k][same]
         with np.errstate(invalid="ignore", divide="ignore"):
@@ -181,7 +193,8 @@ def dump_margins(path):
         return
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
-        json.dump({"what": "measured per-ray parity margins of the HIP path against the reference fixtures / the oracle (tests/parity.py)", "rows": _MARGINS}, f, indent=1)
+        json.dump({"what": "measured per-ray parity margins of the HIP path against the reference fixtures / the oracle (tests/parity.py)", "rows": _MARGINS,
+                   "bins_excluded_from_sum_checks": _BIN_EXCLUSIONS}, f, indent=1)
 
 
 def knife_edge_mask(init, imageplane):

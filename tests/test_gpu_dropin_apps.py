@@ -23,6 +23,19 @@ ENV = dict(os.environ, LD_PRELOAD="/usr/lib/x86_64-linux-gnu/libstdc++.so.6", LD
 COUNT_KEYS = {"DISC_N", "HIT_N", "ESC_N", "NHIT", "DISCRAYS"}     # header cards whose value may move by a chaotic ray
 
 
+def close_to_cpu(test, case, g, w, rtol=1e-6, atol=0.0):
+    """np.testing.assert_allclose at the north-star tolerance, with the measured worst relative difference left in the round's margin record
+    (gpurun_out/parity_margins.json -> profiles/): how close each program's output runs to its bar is on file, not just pass / fail."""
+    import parity
+    g, w = np.asarray(g, dtype=np.float64), np.asarray(w, dtype=np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.where(g == w, 0.0, np.abs(g - w) / np.maximum(np.abs(w), 1e-300))
+    rel = np.where(np.abs(g - w) <= atol, 0.0, rel)
+    worst = float(rel.max()) if rel.size else 0.0
+    parity.record_margin(test, case, {"n_traced": int(rel.size), "n_bad": int((rel > rtol).sum()), "frac_bad": float((rel > rtol).mean()) if rel.size else 0.0, "worst_ok": worst}, rtol)
+    assert worst <= rtol, (test, case, worst, rtol)
+
+
 def need(app):
     path = os.path.join(BUILD, app)
     if not os.path.exists(path):
@@ -52,6 +65,7 @@ def test_emissivity_apps_match_cpu_output(app, arithmetic):
     dcount = np.abs(got[:, 2] - want[:, 2])
     assert dcount.max() <= 1, dcount.max()                          # a chaotic ray may move between neighbouring bins
     same = dcount == 0
+    assert (~same).sum() <= 2, (~same).sum()                        # ... and that is at most one ray (two bins) per table: the sums of every other bin are checked
     for col in (3, 4, 5, 6):
         g, w = got[same, col], want[same, col]
         assert (np.isnan(g) == np.isnan(w)).all()
@@ -73,12 +87,11 @@ def test_imageplane_app_matches_cpu_output(par):
     assert got_cards == fits_lite.header_cards(os.path.join(APPS, par + ".fits"))
     for k in ("DIST", "INCL", "SPIN", "ISCO", "RDISC", "NRAYS", "DISCRAYS"):
         assert got["PRIMARY"]["header"][k] == want["PRIMARY"]["header"][k], k
-    rtol = 1e-6 if par.endswith("rk4") else 1e-5     # RK45 per-ray noise envelope: tests/parity.py
-    for name in list(want)[1:]:
+    for name in list(want)[1:]:           # RK4 and RK45 alike: the north-star 1e-6 on every pixel of every plane
         g, w = got[name]["data"], want[name]["data"]
         assert (np.isnan(g) == np.isnan(w)).all(), name             # NaN pattern (empty pixels) identical
         ok = ~np.isnan(w)
-        np.testing.assert_allclose(g[ok], w[ok], rtol=rtol, atol=1e-12, err_msg=name)
+        close_to_cpu("test_imageplane_app_matches_cpu_output", f"{par}-{name}", g[ok], w[ok], rtol=1e-6, atol=1e-12)
 
 
 @pytest.mark.parametrize("par,app", [("imageplane_isco", "imageplane_disc_image_isco"), ("imageplane_rd", "imageplane_disc_image_rd")])
@@ -124,8 +137,9 @@ def test_rk45_tolerance_sweep_program_matches_cpu_output(tol, fixture):
     assert (got[:, 0] == want[:, 0]).all()
     assert np.abs(got[:, 1] - want[:, 1]).max() <= 1 and np.abs(got[:, 2] - want[:, 2]).max() <= 2      # ray counts: RK4, RK45
     same4, same45 = got[:, 1] == want[:, 1], got[:, 2] == want[:, 2]
-    for col, same, rtol in ((3, same4, 1e-6), (5, same4, 1e-6), (7, same4, 1e-6), (4, same45, 1e-5), (6, same45, 1e-5), (8, same45, 1e-5)):
-        np.testing.assert_allclose(got[same, col], want[same, col], rtol=rtol, err_msg=f"column {col}")
+    assert (~same4).sum() <= 1 and (~same45).sum() <= 2, ((~same4).sum(), (~same45).sum())      # bins left out of the sum check below (a ray moved across an edge)
+    for col, same in ((3, same4), (5, same4), (7, same4), (4, same45), (6, same45), (8, same45)):
+        close_to_cpu("test_rk45_tolerance_sweep_program_matches_cpu_output", f"tol{tol}-column{col}", got[same, col], want[same, col], rtol=1e-6)
 
 
 def test_integrator_perf_report_matches_cpu_statistics():
@@ -171,7 +185,7 @@ def test_reference_self_tests_pass_on_the_hip_path():
 def test_caustic_apps_match_cpu_output(par, app):
     """the caustic applications (ImagePlaneBundles 5-ray bundles / ImagePlane, DiscWithISCO and FlatPlane
     destinations, rdot_flips / equatorial_crossings outputs), unmodified, on the HIP path.  Classification maps must agree on
-    >= 99 % of the pixels (a photon-ring pixel may change image order), hit coordinates to 1e-6 (RK4) / 1e-5 (RK45); det(J)
+    >= 99 % of the pixels (a photon-ring pixel may change image order), hit coordinates to 1e-6 on >= 99 % of them (RK4 and RK45); det(J)
     is a central difference over 1 % of a pixel, i.e. it amplifies end-point differences by ~1e2..1e3, and is held to 1e-3."""
     exe = need(app)
     with tempfile.TemporaryDirectory() as w:
@@ -194,7 +208,7 @@ def test_caustic_apps_match_cpu_output(par, app):
         if name in ("SIGN_J", "ORDER", "HIT", "HIT_PLANE", "ESCAPED", "RDOT_FLIPS", "EQUAT_CROSS"):
             assert (g[ok] == w[ok]).mean() >= 0.99, (name, (g[ok] == w[ok]).mean())
             continue
-        rtol = 1e-3 if name == "DET_J" else (1e-5 if rk45 else 1e-6)
+        rtol = 1e-3 if name == "DET_J" else 1e-6                 # (RK4 and RK45 alike)
         close = np.isclose(g[ok], w[ok], rtol=rtol, atol=1e-9)
         need_frac = 0.97 if name == "DET_J" else 0.99
         if name in ("PHI", "PHI_S"):                       # angles may differ by a 2 pi wrap on the branch cut
@@ -232,6 +246,7 @@ def test_native_emissivity_app_matches_cpu_output(arithmetic):
     dcount = np.abs(got[:, 2] - want[:, 2])
     assert dcount.max() <= 1
     same = dcount == 0
+    assert (~same).sum() <= 2, (~same).sum()
     for col in (3, 4, 5, 6):
         g, w_ = got[same, col], want[same, col]
         assert (np.isnan(g) == np.isnan(w_)).all()
@@ -252,9 +267,8 @@ def test_native_imageplane_app_matches_cpu_output(par):
     golden = os.path.join(APPS, par + ".fits")
     want = {h["name"]: h for h in fits_lite.read(golden)}
     assert size == os.path.getsize(golden) and got_cards == fits_lite.header_cards(golden)      # every header byte, incl. DISCRAYS
-    rtol = 1e-6 if par.endswith("rk4") else 1e-5
     for name in list(want)[1:]:
         g, w_ = got[name]["data"], want[name]["data"]
         assert (np.isnan(g) == np.isnan(w_)).all(), name
         ok = ~np.isnan(w_)
-        np.testing.assert_allclose(g[ok], w_[ok], rtol=rtol, atol=1e-12, err_msg=name)
+        close_to_cpu("test_native_imageplane_app_matches_cpu_output", f"{par}-{name}", g[ok], w_[ok], rtol=1e-6, atol=1e-12)

@@ -115,7 +115,7 @@ def test_emissivity_bins_vs_golden(krlib, case_name, run, flags):
     # the oracle's reducer on the REFERENCE's final rays
     want = oracle_reduce_emissivity(bins, ref_final)
     assert want["disc_count"] > 0
-    assert parity.compare_bins(got, want) == []
+    assert parity.compare_bins(got, want, label=f"test_emissivity_bins_vs_golden[{case_name}-{run}-flags{flags}]") == []
     assert abs(got["disc_count"] - want["disc_count"]) <= parity.BIN_COUNT_SLACK
 
 
@@ -330,7 +330,7 @@ def test_perf_test_grid_vs_oracle(krlib, method, flags):
     parity.record_margin("test_perf_test_grid_vs_oracle", f"ps_h10_5167-{['euler', 'rk4', 'rk45'][method]}-flags{flags}", res, parity.CHAOTIC_FRAC)
     assert res["frac_bad"] <= parity.CHAOTIC_FRAC, res
     bins = gc.emis_bins(spec, nr=30)
-    assert parity.compare_bins(api.reduce_emissivity(bins, out), oracle_reduce_emissivity(bins, want)) == []
+    assert parity.compare_bins(api.reduce_emissivity(bins, out), oracle_reduce_emissivity(bins, want), label=f"test_perf_test_grid_vs_oracle[{method}-flags{flags}]") == []
     if not flags & capi.FLAG_FAST_MATH:
         assert abs(st["steps_total"] - wst["steps_total"]) <= 0.01 * wst["steps_total"]
 
