@@ -38,6 +38,8 @@ template <typename T> struct TraceConsts {
     // a disabled clause gets the value that makes its own comparison false for every ray (r < -inf; step > |inf / phidot|; x > +inf).  Same
     // decisions on every ray, and no uniform lane masks for the compiler to carry (and spill) through the step loop.
     T tstep_rlim_eff;       // max_tstep > 0 ? maxtstep_rlim : -inf
+    // fast path: the words of max_tstep, and the high word of "no cap" -- a number >= 8.9e307 that shares max_tstep's low word (step_fixed)
+    uint32_t tstep_lo, tstep_on_hi, tstep_off_hi;
     T phistep_eff;          // max_phistep > 0 ? max_phistep : +inf
     // ("rlim > 0 && r + rdot step > rlim" needs no constant of its own: with rlim <= 0 the loop condition r < rlim admits no step at all.
     // Likewise "thetalim > 0 && theta + thetadot step > thetalim" compares against theta_hi below: +inf unless thetalim > 0.)
@@ -54,7 +56,7 @@ template <typename T> struct Lane {
     int32_t rdot_sign, thetadot_sign, rdot_flips, eq_cross;
     int32_t steps;          // steps taken in THIS call (the reference's local `steps`)
     int32_t status;
-    int32_t steps0;         // rays[i].steps on entry
+    int32_t steps0;         // rays[i].steps on entry (>= 0 for a traced ray); its SIGN BIT is this call's "always evaluate the NEG_ENERGY flag" mark (energy_guard)
     bool r_was_positive, theta_was_positive;   // per-call locals, raytracer.cpp:767-768
     // RK45 only
     T step;                 // running step size
@@ -69,6 +71,18 @@ template <typename T> struct Lane {
     bool fsal_valid;
     T f_sin2theta, f_rhosq, f_delta, f_pt, f_thetadotsq, f_abs_ptheta;
 };
+
+// The NEG_ENERGY flag, (1 - 2r/rho^2) tdot + (2 a r sin^2/rho^2) phidot < 0 (raytracer.cpp:264-273 / :874-887 / :1403-1410), is the conserved energy k
+// evaluated from tdot and phidot.  Its two terms are <= ~(r^2 + a^2)^2 (k + |h| / r) / (rho^2 Delta) in size, so their rounding errors (1e-16 of the terms)
+// stay far below k -- and the sum cannot come out negative, in the reference or here -- as long as the ray is not within 1e-6 of the horizon, k > 0 and
+// |h| <= 1e6 k.  The per-ray half of that (k, h: constants of the ray) is decided ONCE, when a lane takes the ray, and kept in the sign bit of steps0;
+// the per-step test is then "r - r_h > 1e-6 and the mark is clear" -- two compares, as before the |h| clause existed.
+template <typename T> KR_DEV void energy_guard_set(Lane<T>& s)
+{
+    if (!(s.k > T(0)) || !(kr_abs(s.h) <= T(1e6) * s.k)) s.steps0 |= (int32_t) 0x80000000;       // (NaN k or h: marked)
+}
+template <typename T> KR_DEV bool energy_flag_needed(const Lane<T>& s, T r_minus_horizon) { return !(r_minus_horizon > T(1e-6)) || s.steps0 < 0; }
+template <typename T> KR_DEV int32_t steps_on_entry(const Lane<T>& s) { return s.steps0 & 0x7fffffff; }
 
 // momentum_from_consts, src/include/kerr.h:300-335
 template <typename T>
@@ -168,7 +182,7 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y_rhos
 // depends on it; those, the turning-point logic and the signs are done here as k1_impl does them.  ~70-115 of a trial step's ~1400
 // instructions, on every accepted step; exact.  (Strict arithmetic, double precision.)
 template <typename T>
-KR_DEV bool k1_from_last_stage(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
+KR_DEV bool k1_from_last_stage(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y_rhosq_o = nullptr)
 {
     const T r = s.r, k = s.k, h = s.h;
     const T sin2theta = s.f_sin2theta, rhosq = s.f_rhosq, delta = s.f_delta;
@@ -183,7 +197,8 @@ KR_DEV bool k1_from_last_stage(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
     if (thetadotsq >= 0) s.theta_was_positive = true;
     s.ptheta = s.f_abs_ptheta * s.thetadot_sign;
     T rdotsq = k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta;
-    rdotsq = dv(rdotsq * delta, rhosq);
+    const T y_rhosq = dv_recip(rhosq);                 // (shared with the caller's two flag quotients over rho^2, as in k1_with_flips)
+    rdotsq = dv_y(rdotsq * delta, rhosq, y_rhosq);
     if (rdotsq <= 0 && s.r_was_positive) {
         s.rdot_sign = -s.rdot_sign;
         s.r_was_positive = false;
@@ -194,6 +209,7 @@ KR_DEV bool k1_from_last_stage(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o)
     s.pr = sq(kr_abs(rdotsq)) * s.rdot_sign;
     rhosq_o = rhosq;
     sin2theta_o = sin2theta;
+    if (y_rhosq_o) *y_rhosq_o = y_rhosq;
     return false;
 }
 
@@ -312,8 +328,13 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         step = (kr_abs(dr) * inv_pr) * c.inv_precision;
         if (step > q_th * c.inv_precision) step = q_th * c.inv_theta_precision;
         {
-            const T apt = kr_abs(pt1), aphi = kr_abs(pphi1);
-            const T dt_eff = (s.r < c.tstep_rlim_eff) ? c.max_tstep : T(1e300);
+            // (|phidot| floored at 1e-300: with phidot == 0 exactly -- a = 0 and h = 0 -- the shared quotient below would be 0 x inf = NaN, v_min would
+            // ignore it and the TIME cap would be dropped with it, where the reference's "step > |max_tstep / tdot|" applies it; floored, the
+            // quotient is min(dt 1e-300, dphi |tdot|) / (|tdot| 1e-300) = dt / |tdot|)
+            const T apt = kr_abs(pt1), aphi = abs_floor(pphi1);
+            // the time cap applies inside maxtstep_rlim only: outside, "dt" is a huge number with max_tstep's LOW word (TraceConsts::tstep_off_hi),
+            // so that the choice is one select on the high word instead of two on a 64-bit pair
+            const T dt_eff = __builtin_bit_cast(double, ((unsigned long long) (unsigned) ((s.r < c.tstep_rlim_eff) ? c.tstep_on_hi : c.tstep_off_hi) << 32) | c.tstep_lo);
             const T num = __builtin_fmin(dt_eff * aphi, c.phistep_eff * apt);
             step = __builtin_fmin(step, num * fast_rcp_heur(apt * aphi));
         }
@@ -341,11 +362,13 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
                 if (near_th && s.theta + ptheta1 * step > c.theta_hi) step = kr_abs(lean_div(c.theta_hi - s.theta, ptheta1));
             }
         }
-        if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
+        if (__builtin_amdgcn_ballot_w64(pt1 <= 0) != 0) {        // (inside the ergosphere only: one compare and a scalar branch instead of compare, or, select)
+            if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
+        }
         // (1 - 2r/rho^2) tdot + (2 a r sin^2/rho^2) phidot IS the conserved energy k (= -p_t): analytically it cannot turn negative, and
         // numerically only where its two terms (~ k / Delta) are 1e15 times k.  Away from the horizon, for k > 0, the test is skipped
         // (wave-uniform; a NaN k or r takes the evaluation, whose comparison is then false as in the reference).
-        if (__builtin_amdgcn_ballot_w64(!(dr > T(1e-6)) || !(s.k > T(0))) != 0) {
+        if (__builtin_amdgcn_ballot_w64(energy_flag_needed(s, dr)) != 0) {
             const T two_r_rho = 2 * s.r * aux.inv_rhosq;
             if ((1 - two_r_rho) * pt1 + (two_r_rho * a * aux.sin2theta) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
         }
@@ -377,10 +400,10 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     // flags (:264-273 / :874-887); neither ends the ray
     if (pt1 <= 0) s.status |= KR_STATUS_ERGO;
     // (1 - 2r/rho^2) tdot + (2 a r sin^2/rho^2) phidot is the conserved energy k (= -p_t) evaluated from tdot and phidot: its two terms are
-    // <= ~(r^2 + a^2)^2 k / (rho^2 Delta) in size, so with r - r_horizon > 1e-6 (Delta > 1e-9 for every a < 0.99999) their rounding errors, 1e-16
-    // of the terms, stay below 1e-7 k: for k > 0 the sum cannot come out negative, in the reference or here.  The flag is therefore only
-    // evaluated -- with the reference's operations -- by waves in which some ray is that close to the horizon or has k <= 0 / NaN.
-    if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(!(s.r - c.horizon > T(1e-6)) || !(s.k > T(0))) != 0) {
+    // bounded (energy_guard_set) so that with r - r_horizon > 1e-6 (Delta > 1e-9 for every a < 0.99999), k > 0 and |h| <= 1e6 k the sum cannot come out
+    // negative, in the reference or here.  The flag is therefore only evaluated -- with the reference's operations -- by waves in which some ray is that
+    // close to the horizon or carries the mark.
+    if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(energy_flag_needed(s, s.r - c.horizon)) != 0) {
         if ((1 - dv_y(2 * s.r, rhosq, y_rhosq)) * pt1 + dv_y(2 * a * s.r * sin2theta, rhosq, y_rhosq) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
     }
     }
@@ -475,7 +498,7 @@ KR_DEV int32_t finish_status(Lane<T>& s, const TraceConsts<T>& c)
         s.status |= KR_STATUS_RLIM;
     else if (!USE_DEST && (s.theta >= c.theta_hi || s.theta <= c.theta_lo))       // (tl > 0 && theta >= tl) || (tl < 0 && theta <= |tl|)
         s.status |= KR_STATUS_DEST;
-    int32_t out_steps = s.steps0;
+    int32_t out_steps = steps_on_entry(s);
     if (s.steps > 0) out_steps += s.steps;
     if (s.status & KR_STATUS_STEPLIM) out_steps = -out_steps;
     return out_steps;

@@ -149,27 +149,33 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
                 if (step_t < step_max) step_max = step_t;
             }
         } else {
-        T rhosq, sin2theta;
+        T rhosq, sin2theta, y_rhosq;
         bool flipped;
         if constexpr (sizeof(T) == 8) {
             // wave-uniform: every lane's data from its last accepted stage is valid (else all recompute -- same bits either way)
-            if (__builtin_amdgcn_ballot_w64(!s.fsal_valid) == 0) flipped = k1_from_last_stage<T>(s, a, rhosq, sin2theta);
-            else flipped = k1_with_flips<T, true>(s, a, rhosq, sin2theta);
+            if (__builtin_amdgcn_ballot_w64(!s.fsal_valid) == 0) flipped = k1_from_last_stage<T>(s, a, rhosq, sin2theta, &y_rhosq);
+            else flipped = k1_with_flips<T, true>(s, a, rhosq, sin2theta, &y_rhosq);
         } else {
-            flipped = k1_with_flips<T, true>(s, a, rhosq, sin2theta);
+            flipped = k1_with_flips<T, true>(s, a, rhosq, sin2theta, &y_rhosq);
         }
         if (flipped) return !(s.steps < c.steplim);
-        // flags (:1403-1410): same rhosq / sin2theta values as k1's
+        // flags (:1403-1410): same rhosq / sin2theta values as k1's.  The NEG_ENERGY test is the conserved energy k evaluated from tdot and phidot: away
+        // from the horizon, for k > 0 and |h| <= 1e6 k, its rounding cannot turn the sum negative (energy_guard_set) -- evaluated, with the reference's
+        // operations and k1's refined reciprocal of rho^2, only by waves that hold a ray within 1e-6 of the horizon or one that carries the mark
         if (s.pt <= 0) s.status |= KR_STATUS_ERGO;
-        if ((1 - 2 * s.r / rhosq) * s.pt + (2 * a * s.r * sin2theta / rhosq) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
-        // outer cap (:1421-1434): horizon / phi / t, no MIN_STEP floor afterwards
-        step_max = kr_abs((s.r - c.horizon) / s.pr) / c.precision;
+        if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(energy_flag_needed(s, s.r - c.horizon)) != 0) {
+            if ((1 - dv_y(2 * s.r, rhosq, y_rhosq)) * s.pt + dv_y(2 * a * s.r * sin2theta, rhosq, y_rhosq) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
+        }
+        // outer cap (:1421-1434): horizon / phi / t, no MIN_STEP floor afterwards.  The first quotient keeps the compiler's IEEE division: with
+        // rdot == 0 it must be +inf (so that the other two caps still apply), where the lean chain gives NaN; for the other two, inf and NaN
+        // alike make "cap < step_max" false.  / precision through the host's correctly rounded reciprocal (div_const: same bits).
+        step_max = div_const(kr_abs((s.r - c.horizon) / s.pr), c.precision, c.inv_precision, c.inv_ok);
         {                                                  // max_phistep > 0: otherwise the quotient is inf / NaN and the comparison false
-            const T step_phi = kr_abs(c.phistep_eff / s.pphi);
+            const T step_phi = kr_abs(dv(c.phistep_eff, s.pphi));
             if (step_phi < step_max) step_max = step_phi;
         }
         if (s.r < c.tstep_rlim_eff) {                      // max_tstep > 0 && r < maxtstep_rlim
-            const T step_t = kr_abs(c.max_tstep / s.pt);
+            const T step_t = kr_abs(dv(c.max_tstep, s.pt));
             if (step_t < step_max) step_max = step_t;
         }
         }
@@ -260,6 +266,8 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     }
     if (__builtin_amdgcn_ballot_w64(!surely_saturated) == 0) err_norm = T(1e-4);      // (stands for "some value <= 1.8e-4")
     else err_norm = kr_sqrt(T(0.5) * ((err_r / sc_r) * (err_r / sc_r) + (err_theta / sc_theta) * (err_theta / sc_theta)));
+    // (the compiler's IEEE quotients and root stay here: an infinite scale or norm -- a diverging trial -- must come out as 0 / inf, as in the reference,
+    // where the lean chains would say NaN and end the ray)
 
     // 0.9 (1 / max(err, 1e-10))^0.2 clamped to [0.1, 5] (:1517-1518) IS 5 whenever err <= 1.889e-4 (0.9 x^0.2 >= 5 from x = 5292 on); a ray
     // whose step is set by a cap rather than by its error -- the polar-axis ray's 100 000 steps -- is there at every step, and the

@@ -194,7 +194,16 @@ KR_SC_FN void kr_sincos_fast_core_f64(double x, double& s, double& c);
 KR_SC_FN void kr_sincos_fast_f64(double x, double& s, double& c)
 {
     if (__builtin_expect(!(__builtin_fabs(x) < 1024.0), 0)) {
-        kr_sincos_f64(x, s, c);
+        // what kr_sincos_f64 does with such an argument -- the out-of-line library routine -- called directly: going through kr_sincos_f64 inlined
+        // the correctly rounded kernel, which this path never reaches, into every fast kernel, and its ~25 coefficients (hoisted into vector
+        // registers with everything else) shared high dwords with this routine's: 5 v_mov_b32 per evaluation to piece the pairs together
+        double ls, lc;
+        kr_sincos_libm_f64(x, &ls, &lc);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ls), "+v"(lc));
+#endif
+        s = ls;
+        c = lc;
         return;
     }
     kr_sincos_fast_core_f64(x, s, c);

@@ -143,6 +143,8 @@ template <typename T> KR_DEV unsigned long long wave_sum(unsigned long long v)
 // Resident waves per SIMD the register allocation must allow: HOG 1 (the scheduler may trade registers for ILP; capping it at (1, 1) measured 2 %
 // slower), RK4 3 (<= 168 VGPRs), RK45 2, Euler 4 (its step is short and branchy: at 3 waves per SIMD the vector unit is 78 % busy; 1e7 rays
 // 38.5 / 31.4 / 28.3 ms at 2 / 3 / 4 resident waves, profiles/r03_ab_experiments.txt).
+// (Euler at 5: the fast kernel fits -- 96 registers, 32 B of spills -- and an all-fast 1e7-ray launch gains 2.5 %, but the hybrid pass and the
+// returning-radiation batches, whose side launches share the chip with it, lose 1-3 %: profiles/r04_ab_experiments.txt.)
 #define KR_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(HOG ? 1 : METHOD == KR_RK4 ? 3 : METHOD == KR_RK45 ? 2 : 4, 8)))
 // everything one trace launch works on; a batch of traces hands the kernel an array of these (trace_multi_kernel)
 template <typename T> struct TraceDesc {
@@ -178,13 +180,12 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
     unsigned long long my_steps = 0, my_traced = 0;
     int32_t my_longest = 0;     // most steps any of this lane's rays took in this call
     uint32_t my_attempts = 0, my_rejects = 0, my_stationary = 0, my_creep = 0;
-    unsigned prio_tick = 0;
 
 #if KR_OCC_STATS
     unsigned long long occ_iters = 0, occ_tail_iters = 0, occ_tail_steps = 0, occ_refills = 0, occ_refill_lanes = 0;
 #endif
     for (;;) {
-        const unsigned long long need = __ballot(!have);
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(!have);      // (not __ballot: that one takes its predicate through a vector register and a compare)
         const int n_need = __popcll(need);
         const bool any_have = (need != ~0ull);
 
@@ -202,6 +203,26 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
                 pend = false;
             }
             if (leaving) break;
+            // The launch cannot end before its longest ray does, and a ray advances one step per iteration of ITS wave: a wave that carries a long
+            // ray (orbiting / polar-axis rays: 2e4..1e7 steps against a median of ~450) is given issue priority over its SIMD neighbours so that the
+            // critical path runs at single-wave speed instead of at 1/(waves per SIMD) of it -- graded: the longer the wave's oldest ray, the higher
+            // its priority (0..3), so that the rays that define the critical path do not share their level with the many merely "longish" ones.
+            // Re-evaluated here, at the queue visits (a wave that carries a long ray keeps visiting for its other 63 lanes until the queue is empty;
+            // a counter in the step loop cost three vector instructions per step).  A wave that owns its SIMD (HOG) has nobody to overtake.
+            if constexpr (!HOG) {
+                const int32_t st = have ? s.steps : 0;
+                auto any = [](bool x) { return __builtin_amdgcn_ballot_w64(x) != 0; };
+                const int want_prio = any(st > 8 * kLongRaySteps) ? 3 : any(st > 3 * kLongRaySteps) ? 2 : any(st > kLongRaySteps) ? 1 : 0;
+                if (want_prio != has_prio) {
+                    has_prio = want_prio;
+                    switch (want_prio) {
+                        case 3: __builtin_amdgcn_s_setprio(3); break;
+                        case 2: __builtin_amdgcn_s_setprio(2); break;
+                        case 1: __builtin_amdgcn_s_setprio(1); break;
+                        default: __builtin_amdgcn_s_setprio(0); break;
+                    }
+                }
+            }
 #if KR_OCC_STATS
             ++occ_refills; occ_refill_lanes += n_need;
 #endif
@@ -235,6 +256,7 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
                         s.creep_run = 0;
                         s.creep_mode = false;
                         s.fsal_valid = false;
+                        energy_guard_set(s);
                         if (METHOD == KR_RK45) rk45_seed(s, c);
                         if (!loop_cond<T, USE_DEST>(s, c)) {
                             // zero-iteration call: only the epilogue runs (at the next visit)
@@ -247,31 +269,10 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
             continue;   // re-evaluate the ballots (skipped / zero-iteration rays leave lanes free)
         }
 
-        if (!HOG && (++prio_tick & 15) == 0)   // (a wave that owns its SIMD has nobody to take priority over; the thresholds are thousands of steps)
-        // The launch cannot end before its longest ray does, and a ray advances one step per iteration of ITS wave:
-        // a wave that carries a long ray (orbiting / polar-axis rays: 2e4..1e7 steps against a median of ~450) is
-        // given issue priority over its SIMD neighbours so that the critical path runs at single-wave speed
-        // instead of at 1/(waves per SIMD) of it.  Wave-uniform, re-evaluated only when the ballot changes.
-        {
-            // graded: the longer the wave's oldest ray, the higher its priority (0..3), so the rays that define the
-            // critical path do not have to share their priority level with the many merely "longish" ones
-            const int32_t st = have ? s.steps : 0;
-            const int want_prio = __any(st > 8 * kLongRaySteps) ? 3 : __any(st > 3 * kLongRaySteps) ? 2 : __any(st > kLongRaySteps) ? 1 : 0;
-            if (want_prio != has_prio) {
-                has_prio = want_prio;
-                switch (want_prio) {
-                    case 3: __builtin_amdgcn_s_setprio(3); break;
-                    case 2: __builtin_amdgcn_s_setprio(2); break;
-                    case 1: __builtin_amdgcn_s_setprio(1); break;
-                    default: __builtin_amdgcn_s_setprio(0); break;
-                }
-            }
-        }
-
         int replay_batch = 1;
         if constexpr (METHOD == KR_RK45 && sizeof(T) == 8) {
             // the tail of an RK45 launch is waves that hold nothing but creeping captured rays: they take 16 cheap steps per iteration
-            if (!__any(have && !s.creep_mode)) replay_batch = 16;
+            if (!__any(have && !s.creep_mode)) replay_batch = 16;      // (__any, not the ballot builtin: with the builtin this kernel's allocation came out 19 % slower)
         }
 #if KR_OCC_STATS
         ++occ_iters;
@@ -610,6 +611,12 @@ TraceConsts<T> make_consts(const kr_params* p, int steplim)
     c.theta_lo = c.thetalim < 0 ? std::fabs(c.thetalim) : -inf;
     c.theta_hi = c.thetalim > 0 ? c.thetalim : (c.thetalim <= 0 ? inf : -inf);
     c.tstep_rlim_eff = c.max_tstep > 0 ? c.maxtstep_rlim : -inf;
+    {
+        unsigned long long bits;
+        const double mt = (double) p->max_tstep;
+        std::memcpy(&bits, &mt, sizeof bits);
+        c.tstep_lo = (uint32_t) bits; c.tstep_on_hi = (uint32_t) (bits >> 32); c.tstep_off_hi = 0x7FE00000u;
+    }
     c.phistep_eff = c.max_phistep > 0 ? c.max_phistep : inf;
     return c;
 }

@@ -510,6 +510,27 @@ def test_degenerate_denominators_match_oracle(krlib):
         assert (~np.isfinite(out["r"][bad])).all()
 
 
+def test_fast_arithmetic_keeps_the_time_cap_when_phidot_is_zero(krlib):
+    """Pure KR_FLAG_FAST_MATH with phidot == 0 exactly (a = 0, h = 0): the fixed-step integrators' time and azimuth caps share one reciprocal,
+    min(dt |phidot|, dphi |tdot|) / (|tdot| |phidot|), which would be 0 x inf = NaN there -- v_min would drop it and with it the TIME cap, which the
+    reference applies inside maxtstep_rlim (raytracer.cpp:862-865: step > |max_tstep / tdot|).  |phidot| is floored at 1e-300 (kr_device.hpp::step_fixed):
+    these rays must then take the reference's steps.  (Under the hybrid launch they go to the strict kernel anyway: |h| < 1e-13.)"""
+    spec = ol.pointsource_spec([0.0, 8.0, 0.7, 0.0], 0.0, 0.0, 0.2, 0.2, cosalpha0=-0.995, cosalphamax=0.995, beta0=-np.pi, betamax=np.pi)
+    init = ol.oracle_pointsource(spec)
+    live = init["steps"] == 0
+    init["h"][live] = 0.0                        # exactly zero axial angular momentum at a = 0 -> phidot exactly 0 along the whole ray
+    for method in (capi.EULER, capi.RK4):
+        p = capi.default_params(0.0)
+        p.integrator, p.r_max, p.steplim = method, 1000.0, 200000
+        assert p.max_tstep > 0 and p.maxtstep_rlim > 8.0            # the cap is active where these rays start
+        want, wst = ol.oracle_trace(p, init)
+        out, st = api.trace(capi.copy_params(p, flags=capi.FLAG_FAST_MATH), init)
+        res = parity.compare_rays(out, want, rtol=parity.rtol_for(p), steps_slack=2)
+        parity.record_margin("test_fast_arithmetic_keeps_the_time_cap_when_phidot_is_zero", ["euler", "rk4"][method], res, parity.CHAOTIC_FRAC)
+        assert res["n_traced"] > 100 and res["frac_bad"] <= parity.CHAOTIC_FRAC, res
+        assert abs(st["steps_total"] - wst["steps_total"]) <= 2 * res["n_traced"], (st["steps_total"], wst["steps_total"])
+
+
 def test_return_radiation_vs_oracle(krlib):
     """BASELINE configs[4] semantics (disc -> disc returning radiation, per-radius relaunch): source on the disc at r_s,
     Keplerian, beta in [0, pi), Euler to 1.1 r_esc, then the escape / return / lost classification
