@@ -960,6 +960,10 @@ def cpu_baseline_imageplane(args, capi, api, wl):
         "max_count_diff": int(np.abs(dev_planes["nrays"].astype(np.int64) - w_n).max()),
         "disc_rays_device": int(round(float(hp[-1]))), "disc_rays_cpu": int(dc.value), "max_rel_diff_of_pixel_sums(RADIUS, ENSHIFT, FLUX, TIME)": pworst,
         "rk_steps_device": int(pst["steps_total"]), "rk_steps_cpu": steps, "tolerance": 1e-6}
+    planes_check = {"image": f"{img}x{img}", "lit_pixels": int((w_n > 0).sum()), "pixels_count_mismatch": int((~same).sum()), "disc_rays_cpu": int(dc.value),
+                    "disc_rays_gpu": int(got["disc_count"]), "max_rel_diff_of_pixel_sums(RADIUS, ENSHIFT, FLUX, TIME)": worst, "tolerance": 1e-6,
+                    "ray_integer_fields_differ": ints_differ,
+                    "strict_arithmetic_bit_identical_frac(t, r, theta, phi, redshift, integer fields)": strict_bits}
     return {"value": int(live.sum()) / wall, "unit": "rays/s", "cores": cores, "kind": kind, "steps_per_sec": steps / wall, "wall_s": wall,
             "sample": f"same image plane on a {N + 1}x{N + 1} ray grid: {int(live.sum())} rays, {steps} steps, run_raytrace only",
             "pipeline_planes_check": pipeline_planes_check, "planes_check": planes_check}

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["kr_trace.hip", "kr_post.hip", "kr_capi.hip"]
-HEADERS = ["kr_device.hpp", "kr_arith.hpp", "kr_fast.hpp", "kr_rk45.hpp", "kr_post_device.hpp", "kr_sincos.hpp", "kr_replay.hpp", "kr_common.hpp", os.path.join("..", "..", "include", "kr_trace.h")]
+HEADERS = ["kr_device.hpp", "kr_crmath.hpp", "kr_arith.hpp", "kr_fast.hpp", "kr_rk45.hpp", "kr_post_device.hpp", "kr_sincos.hpp", "kr_replay.hpp", "kr_common.hpp", os.path.join("..", "..", "include", "kr_trace.h")]
 LIB = os.path.join(CSRC, "libkrtrace.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",

@@ -112,8 +112,6 @@ KR_DEV double kr_sin(double x) { double s, c; kr_sincos_f64(x, s, c); return s; 
 KR_DEV float kr_sin(float x) { float s, c; kr_sincos(x, s, c); return s; }
 KR_DEV double kr_cos(double x) { double s, c; kr_sincos_f64(x, s, c); return c; }
 KR_DEV float kr_cos(float x) { float s, c; kr_sincos(x, s, c); return c; }
-KR_DEV double kr_tan(double x) { return ::tan(x); }
-KR_DEV float kr_tan(float x) { return (float) ::tan((double) x); }
 KR_DEV double kr_pow(double x, double y) { return ::pow(x, y); }
 KR_DEV float kr_pow(float x, float y) { return (float) ::pow((double) x, (double) y); }
 
@@ -145,9 +143,6 @@ KR_DEV double fifth_root_for_controller(double x)
 }
 KR_DEV float fifth_root_for_controller(float x) { return (float) ::pow((double) x, (double) 0.2f); }
 KR_DEV double kr_log(double x) { return ::log(x); }
-KR_DEV double kr_acos(double x) { return ::acos(x); }
-KR_DEV double kr_asin(double x) { return ::asin(x); }
-KR_DEV double kr_atan2(double y, double x) { return ::atan2(y, x); }
 // std::max / std::min operand semantics (they decide what a NaN operand does; raytracer.cpp:1512-1533)
 template <typename T> KR_DEV T std_max(T a, T b) { return (a < b) ? b : a; }
 template <typename T> KR_DEV T std_min(T a, T b) { return (b < a) ? b : a; }

@@ -22,6 +22,7 @@
 #include "kr_common.hpp"
 #include "kr_device.hpp"
 #include "kr_post_device.hpp"
+#include "kr_crmath.hpp"
 
 namespace kr {
 
@@ -171,7 +172,13 @@ pointsource_init_emit_multi_kernel(SourceChunk c, int reverse, int projradius)
 }
 
 // ---- ImagePlane ctor + init_image_plane (imageplane.cpp:11-121) ---------------------------------------------
-KR_DEV kr_ray_f64 imageplane_ray(const kr_imageplane& s, long long n_grid, int Ny, double a, double D, double incl, double phi0, long long ix)
+// sin / cos of the inclination come from the host's C library (one angle per plane: PlaneTrig); the per-ray acos, atan2, asin and tan -- N^2 distinct
+// arguments, nothing to tabulate -- are kr_crmath.hpp's correctly rounded routines, sin / cos kr_sincos.hpp's: a device-built ray then differs from
+// the reference constructor's only where the host library itself is not correctly rounded (~1e-3 of the rays in some last bit; the device library's
+// 1-2 ulp routines left 21-25 % of the rays with another phi and 4-7 % with another theta or Q).
+struct PlaneTrig { double sin_incl, cos_incl; };
+
+KR_DEV kr_ray_f64 imageplane_ray(const kr_imageplane& s, const PlaneTrig& pt_, long long n_grid, int Ny, double a, double D, double phi0, long long ix)
 {
     kr_ray_f64 ray;
         memset(&ray, 0, sizeof(ray));
@@ -180,14 +187,14 @@ KR_DEV kr_ray_f64 imageplane_ray(const kr_imageplane& s, long long n_grid, int N
             const int i = (int) (ix / Ny), j = (int) (ix % Ny);
             const double x = s.x0 + i * s.dy;            // sic: dy, imageplane.cpp:43
             const double y = s.y0 + j * s.dy;
-            const double si = kr_sin(incl), ci = kr_cos(incl);
+            const double si = pt_.sin_incl, ci = pt_.cos_incl;
 
             const double r = kr_sqrt(D * D + x * x + y * y);
-            const double theta = kr_acos((D * ci + y * si) / r);
-            const double phi = phi0 + kr_atan2(x, D * si - y * ci);
+            const double theta = krcr::kr_acos_cr((D * ci + y * si) / r);
+            const double phi = phi0 + krcr::kr_atan2_cr(x, D * si - y * ci);
 
             const double pr = D / r;
-            const double ptheta = kr_sin(kr_acos(D / r)) / r;
+            const double ptheta = kr_sin(krcr::kr_acos_cr(D / r)) / r;
             const double pphi = x * si / (x * x + (D * si - y * ci) * (D * si - y * ci));
 
             const double st = kr_sin(theta), ct = kr_cos(theta);
@@ -210,11 +217,11 @@ KR_DEV kr_ray_f64 imageplane_ray(const kr_imageplane& s, long long n_grid, int N
             ray.k = 1;                                   // calculate_constants_from_p's k/h/Q are overwritten, :100-113
 
             const double b = kr_sqrt(x * x + y * y);
-            double beta = kr_asin(y / b);
+            double beta = krcr::kr_asin_cr(y / b);
             if (x < 0) beta = kPi - beta;
             const double h = -1. * b * si * kr_cos(beta);
             const double ltheta = b * kr_sin(beta);
-            const double tt = kr_tan(theta);
+            const double tt = krcr::kr_tan_cr(theta);
             ray.h = h;
             ray.Q = (ltheta * ltheta) - (a * ct) * (a * ct) + ((h / tt)) * ((h / tt));
             ray.thetadot_sign = (ltheta >= 0) ? 1 : -1;
@@ -226,33 +233,33 @@ KR_DEV kr_ray_f64 imageplane_ray(const kr_imageplane& s, long long n_grid, int N
 }
 
 __global__ void __launch_bounds__(kBlock)
-imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny, long long first, long long stride)
+imageplane_init_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, PlaneTrig tr, int Nx, int Ny, long long first, long long stride)
 {
     const long long n_grid = (long long) Nx * Ny;
     const double a = -1 * s.spin;                       // imageplane.cpp:12
-    const double D = s.dist, incl = s.inc_deg * kPi / 180, phi0 = s.phi0;
+    const double D = s.dist, phi0 = s.phi0;
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock)
-        rays[slot] = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, first + slot * stride);
+        rays[slot] = imageplane_ray(s, tr, n_grid, Ny, a, D, phi0, first + slot * stride);
 }
 
 // ---- fused prologue of the image pipeline: ImagePlane ctor + redshift_start(V, reverse, projradius) in one pass; `spin` is the
 //      Raytracer member (the ImagePlane has negated it), as for kr_redshift_start_dev_f64 -----------------------------------
 __global__ void __launch_bounds__(kBlock)
-imageplane_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, int Nx, int Ny, long long first, long long stride, long long run,
+imageplane_init_emit_kernel(kr_ray_f64* __restrict__ rays, long long n, kr_imageplane s, PlaneTrig tr, int Nx, int Ny, long long first, long long stride, long long run,
                             double spin, double V, int reverse, int projradius)
 {
     const long long n_grid = (long long) Nx * Ny;
     const double a = -1 * s.spin;
-    const double D = s.dist, incl = s.inc_deg * kPi / 180, phi0 = s.phi0;
+    const double D = s.dist, phi0 = s.phi0;
     const double am = reverse ? -1 * spin : spin;
     if (V == -1) {
-        const kr_ray_f64 r0 = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, 0);      // source ray 0 (raytracer.cpp:389-393), not the shard's first
+        const kr_ray_f64 r0 = imageplane_ray(s, tr, n_grid, Ny, a, D, phi0, 0);      // source ray 0 (raytracer.cpp:389-393), not the shard's first
         V = keplerian_V<double>(am, r0.r, r0.theta, projradius != 0);
     }
     for (long long slot = blockIdx.x * (long long) kBlock + threadIdx.x; slot < n; slot += (long long) gridDim.x * kBlock) {
         // slot -> source ray: runs of `run` consecutive rays, `stride` apart (run = 1: plain ray-cyclic)
         const long long src = (run == 1) ? first + slot * stride : first + (slot / run) * stride + (slot % run);
-        kr_ray_f64 ray = imageplane_ray(s, n_grid, Ny, a, D, incl, phi0, src);
+        kr_ray_f64 ray = imageplane_ray(s, tr, n_grid, Ny, a, D, phi0, src);
         ray.emit = emit_value(ray, spin, am, V, reverse);
         rays[slot] = ray;
     }
@@ -407,7 +414,7 @@ KR_DEV void reduce_return_body(kr_ray_f64* __restrict__ rays, long long n, const
             if (!(wrapped == phi) && wrapped == wrapped) { ray->phi = wrapped; phi = wrapped; }
         }
         if (!(ray->steps > 0)) continue;
-        const double alpha = kr_acos(ray->alpha);          // rays[].alpha holds cos(alpha)
+        const double alpha = krcr::kr_acos_cr(ray->alpha);  // rays[].alpha holds cos(alpha)
         const double sasb = kr_abs(kr_sin(alpha) * kr_sin(ray->beta));
         double w = b.plane_iso ? sasb : 1;
         if (b.limb) w *= 1 + 2.06 * sasb;
@@ -651,6 +658,15 @@ int pointsource_init_emit_dev(const kr_pointsource* s, void* d, int64_t n, int64
     return KR_OK;
 }
 
+// sin / cos of the plane's inclination with the host's C library (sincos(): see angle_values) at the reference's own argument, incl * M_PI / 180
+// (imageplane.cpp:23)
+static PlaneTrig plane_trig(const kr_imageplane* s)
+{
+    PlaneTrig t;
+    ::sincos(s->inc_deg * M_PI / 180, &t.sin_incl, &t.cos_incl);
+    return t;
+}
+
 int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t first, int64_t stride, hipStream_t st)
 {
     int32_t nx = 0, ny = 0;
@@ -658,7 +674,7 @@ int imageplane_init_dev(const kr_imageplane* s, void* d, int64_t n, int64_t firs
     if (first < 0 || stride < 1) { set_error("kr_imageplane_init: bad first/stride"); return KR_EINVAL; }
     if (first == 0 && stride == 1 && n < total) { set_error("kr_imageplane_init: n smaller than kr_imageplane_count()"); return KR_EINVAL; }
     if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(imageplane_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nx, ny, (long long) first, (long long) stride);
+    hipLaunchKernelGGL(imageplane_init_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, plane_trig(s), nx, ny, (long long) first, (long long) stride);
     KR_LAUNCH_CHECK();
     return KR_OK;
 }
@@ -670,7 +686,7 @@ int imageplane_init_emit_dev(const kr_imageplane* s, void* d, int64_t n, int64_t
     kr_imageplane_count(s, &nx, &ny);
     if (first < 0 || stride < 1 || run < 1 || run > stride) { set_error("kr_imageplane_init_emit: bad first/stride/run"); return KR_EINVAL; }
     if (n <= 0) return KR_OK;
-    hipLaunchKernelGGL(imageplane_init_emit_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, nx, ny, (long long) first,
+    hipLaunchKernelGGL(imageplane_init_emit_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, (kr_ray_f64*) d, (long long) n, *s, plane_trig(s), nx, ny, (long long) first,
                        (long long) stride, (long long) run, spin, V, reverse, projradius);
     KR_LAUNCH_CHECK();
     return KR_OK;

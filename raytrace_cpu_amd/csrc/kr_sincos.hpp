@@ -83,7 +83,8 @@ KR_SC_FN void kr_sincos_libm_f64(double x, double* s, double* c) { sincos(x, s, 
 // the strict path differ from glibc only where glibc itself is not correctly rounded (0.01-0.26 % of arguments; the fdlibm kernels
 // this replaces: 3-5 %).  ~95 fp64 instructions for the pair instead of ~68: the TwoSum / TwoProd sequences below rely on
 // -ffp-contract=off (every fma is spelled out).
-KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
+// (the pairs sh + sl and ch + cl BEFORE the final rounding: kr_crmath.hpp's tan divides them)
+KR_SC_FN void kr_sincos_cr_core_pairs(double r, double y, double& sh_o, double& sl_o, double& ch_o, double& cl_o)
 {
     const double zh = r * r, zl = __builtin_fma(r, r, -zh);
     // sin(r + y) = r + y cos r + r^3 (S1 + z (S2 + z T(z)))
@@ -125,10 +126,17 @@ KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
         const double c1 = eh + ph;                                                                // cos r and sin r to double precision:
         const double sh = r + s_ph;                                                               // enough for the y terms
         const double c2 = ((eh - c1) + ph) + (((el - 0.5 * zl) + pl) - sh * y);
-        cr = c1 + c2;
         const double sl = ((r - sh) + s_ph) + (s_pl + c1 * y);
-        sr = sh + sl;
+        sh_o = sh; sl_o = sl; ch_o = c1; cl_o = c2;
     }
+}
+
+KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
+{
+    double sh, sl, ch, cl;
+    kr_sincos_cr_core_pairs(r, y, sh, sl, ch, cl);
+    cr = ch + cl;
+    sr = sh + sl;
 }
 
 // sin and cos of a polar angle, correctly rounded in practice (what every strict-arithmetic caller uses: the integrators' stages, the O(N) passes,

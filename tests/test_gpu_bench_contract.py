@@ -78,3 +78,25 @@ def test_summaries_agree_with_and_without_the_collective_path(extra, keys):
     for k in keys:
         assert plain[k] == dist[k] and plain[k] > 0, (k, plain[k], dist[k])
     assert dist["rccl_ranks"] == 1 and dist["rk_steps_per_launch"] == plain["rk_steps_per_launch"]
+
+
+@pytest.mark.parametrize("workload,key,rays", [("emissivity", "pipeline_bins_check", "4e5"), ("imageplane", "pipeline_planes_check", "2.5e5")])
+def test_cpu_baseline_leg_checks_the_timed_pipeline(workload, key, rays):
+    """bench.py's cpu_baseline leg on a small sample: the line carries `cpu_baseline` with its check of the TIMED, device-resident pipeline
+    (device-built rays, fused passes) beside the checks of the reference-constructed rays -- for the PointSource every bin count, the disc-ray count
+    and the step total equal the CPU's (the device constructor carries the reference's bits)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--rays", rays, "--cpu-sample-rays", "60000", "--steps", "1", "--warmup", "1",
+                        "--no-fast-math-extra"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1
+    chk = cb[key]
+    if workload == "emissivity":
+        assert chk["bins_count_mismatch"] == 0 and chk["rk_steps_equal"] and chk["disc_rays_device"] == chk["disc_rays_cpu"] > 1000, chk
+        assert chk["max_rel_diff_on_matching_bins"] <= 1e-6
+    else:
+        # device-built image-plane rays differ from the reference constructor's where glibc is not correctly rounded (~1e-3 of the rays, in a last bit)
+        assert chk["disc_rays_cpu"] > 1000 and abs(chk["disc_rays_device"] - chk["disc_rays_cpu"]) <= 2, chk
+        assert chk["pixels_count_mismatch"] <= 4, chk
+        assert max(chk["max_rel_diff_of_pixel_sums(RADIUS, ENSHIFT, FLUX, TIME)"].values()) <= 1e-6, chk

@@ -182,9 +182,14 @@ def test_source_init_and_redshift_start(krlib, case_name):
         np.testing.assert_allclose(rays[f][ok], want[f][ok], rtol=1e-11, atol=1e-13, err_msg=f)
         assert np.isnan(rays[f][live & np.isnan(want[f])]).all(), f
     # how many records carry the reference's bits (what is left: acos / atan2 of the device library, glibc's last-bit choices in sin / cos)
-    same = {f: float((rays[f][live].view(np.int64) == want[f][live].view(np.int64)).mean()) for f in ("k", "h", "Q", "emit", "theta", "phi")}
+    same = {f: float(((rays[f][live].view(np.int64) == want[f][live].view(np.int64)) | (np.isnan(rays[f][live]) & np.isnan(want[f][live]))).mean()) for f in ("k", "h", "Q", "emit", "theta", "phi")}
     parity.record_margin("test_source_init_and_redshift_start", case_name, {"n_traced": int(live.sum()), "n_bad": 0, "frac_bad": 0.0, "worst_ok": None},
                          **{f"frac_bit_identical_{f}": v for f, v in same.items()})
+    if gc.is_imageplane(case):
+        # ImagePlane: N^2 distinct arguments of acos / atan2 / asin / tan, evaluated on the device by correctly rounded routines (kr_crmath.hpp): a record
+        # differs from the reference constructor's only where glibc itself is not correctly rounded (per call: 0.06-0.2 % of arguments)
+        for f, floor in (("theta", 0.99), ("phi", 0.99), ("Q", 0.98), ("h", 0.99), ("k", 1.0), ("emit", 0.99)):
+            assert same[f] >= floor, (f, same[f])
     if not gc.is_imageplane(case):
         # PointSource: the constructor's sin / cos / acos / tan values come from host-built tables (glibc, as in the reference) and the rest is
         # IEEE + - x / sqrt on both sides -- every field of every device-built record carries the reference's bits (pointsource.cpp:30-64,
