@@ -60,7 +60,12 @@ for v, cs in per.items():
     c = {k: sum(x) / len(x) for k, x in cs.items()}
     hog = v.rstrip(">").split(",")[-2].strip() == "true" if v.count(",") >= 5 else False        # <T, METHOD, USE_DEST, FAST, HOG, REFILL>
     units = side.get("work_units_strict_side") if hog else (units_total - (side.get("work_units_strict_side") or 0)) if side else units_total
-    k = {"dispatch": meta[v], "duration": dur.get(v), "counters_per_launch": c, "is_strict_side_launch": hog, "work_units_of_this_launch": units}
+    # a workload that launches a variant several times per pass (the returning-radiation groups): the counters are per-launch averages, the work units per pass
+    passes = 3                                                   # --warmup 1 --steps 2
+    launches_per_pass = max(1, round((dur.get(v) or {}).get("calls", passes) / passes))
+    if units:
+        units = units / launches_per_pass
+    k = {"dispatch": meta[v], "duration": dur.get(v), "counters_per_launch": c, "is_strict_side_launch": hog, "launches_per_pass": launches_per_pass, "work_units_per_launch": units}
     der = {}
     if units:
         for name, key in (("valu_wave_instructions_per_wave_step(x64 lanes / work units)", "SQ_INSTS_VALU"), ("salu_per_wave_step", "SQ_INSTS_SALU"), ("branches_per_wave_step", "SQ_INSTS_BRANCH"),
