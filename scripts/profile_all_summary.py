@@ -97,8 +97,8 @@ json.dump(res, open(out, "w"), indent=1)
 # HBM traffic of the trace kernels per pass (what bench.py's roofline.traffic_from_profile quotes)
 tfile = os.path.join(os.path.dirname(src), "trace_kernel_hbm_traffic.json")
 t = json.load(open(tfile)) if os.path.exists(tfile) else {}
-rd = sum(k["counters_per_launch"].get("FETCH_SIZE", 0) for k in res["kernels"].values()) * 1024
-wr = sum(k["counters_per_launch"].get("WRITE_SIZE", 0) for k in res["kernels"].values()) * 1024
+rd = sum(k["counters_per_launch"].get("FETCH_SIZE", 0) * k.get("launches_per_pass", 1) for k in res["kernels"].values()) * 1024
+wr = sum(k["counters_per_launch"].get("WRITE_SIZE", 0) * k.get("launches_per_pass", 1) for k in res["kernels"].values()) * 1024
 key = {"rk4": "emissivity_rk4", "rk45": "emissivity_rk45", "euler": "emissivity_euler", "imageplane": "imageplane_rk4", "return_radiation": "return_radiation_euler"}[wl]
 t[key] = {"read_bytes_raw(FETCH_SIZE x 1024)": rd, "read_bytes_x2(gfx950 correction for wide coalesced reads)": 2 * rd, "write_bytes(WRITE_SIZE x 1024)": wr,
           "algorithmic_bytes(288 B x rays traced)": 288 * (b.get("config", {}).get("rays_per_gpu") or 0)}
