@@ -54,3 +54,32 @@ def test_hybrid_launch_reproduces_integer_outcomes_away_from_baseline(krlib, sou
             differ |= got[k] != want[k]
         n_bad = int((valid & differ).sum())
         assert n_bad <= allowed, (tag, mode, n_bad, np.flatnonzero(valid & differ)[:10].tolist())
+
+
+@pytest.mark.parametrize("incl,spin,dist,half,phi0", [(5.0, 0.9, 10000.0, 30.0, 0.0), (45.0, 0.5, 10000.0, 60.0, 0.3), (80.0, 0.998, 10000.0, 30.0, 0.0), (89.5, 0.998, 1000.0, 20.0, -1.0), (120.0, 0.0, 5000.0, 15.0, 2.0)])
+def test_device_imageplane_constructor_carries_the_reference_bits(krlib, incl, spin, dist, half, phi0):
+    """The device ImagePlane constructor away from the fixtures' geometry: ~2.5e5 rays per plane at five inclinations (below, on and beyond the
+    equatorial side), spins, distances and azimuth offsets, against the oracle's constructor (== the compiled reference's: tests/test_oracle_vs_ref.py,
+    tests/test_host_constructors.py).  Its acos / atan2 / asin / tan are correctly rounded (kr_crmath.hpp), sin / cos too, the rest is IEEE: a field may
+    differ only where glibc's own routine is not correctly rounded (measured per call: 0.06-0.2 % of arguments), so >= 99 % of the rays must carry the
+    reference's bits in EVERY field, and no field may differ by more than an ulp or two of its scale."""
+    n = int(math.sqrt(RAYS)) | 1
+    spec = ol.imageplane_spec(dist, incl, -half, half, 2 * half / n, -half, half, 2 * half / n, spin, phi0=phi0)
+    want = ol.oracle_imageplane(spec)
+    got = api.imageplane_init(spec)
+    assert len(got) == len(want) > 2e5 and np.array_equal(got["steps"], want["steps"])
+    live = want["steps"] == 0
+    all_same = live.copy()
+    for f in ("t", "r", "theta", "phi", "pt", "pr", "ptheta", "pphi", "k", "h", "Q", "alpha", "beta"):
+        g, w = got[f][live], want[f][live]
+        same = (g.view(np.int64) == w.view(np.int64)) | (np.isnan(g) & np.isnan(w))
+        all_same[live] &= same
+        assert same.mean() >= 0.99, (f, same.mean())
+        ok = ~np.isnan(w)
+        np.testing.assert_allclose(g[ok], w[ok], rtol=1e-13, atol=1e-13 * max(1.0, float(np.nanmax(np.abs(w)))), err_msg=f)
+    for f in ("rdot_sign", "thetadot_sign", "status"):
+        assert np.array_equal(got[f][live], want[f][live]), f
+    import parity
+    parity.record_margin("test_device_imageplane_constructor_carries_the_reference_bits", f"incl{incl}-a{spin}", {"n_traced": int(live.sum()), "n_bad": int((live & ~all_same).sum()),
+                         "frac_bad": float((live & ~all_same).sum() / live.sum()), "worst_ok": None}, frac_bit_identical_every_field=float(all_same[live].mean()))
+    assert all_same[live].mean() >= 0.99, all_same[live].mean()
