@@ -377,7 +377,8 @@ int kr_post_return_batch_dev_f64(int32_t count, double lo, double hi, const kr_r
 /* out[i] = op(a[i], b[i]) evaluated ON THE DEVICE with the exact primitive the trace kernel uses (host pointers):
  * 0 a/b (compiler IEEE)  1 a/b (lean IEEE chain of the strict path)  2 sqrt(a) (compiler)  3 sqrt(a) (lean)
  * 4 sin(a)  5 cos(a) (compact polar-angle sincos)  6 a*rcp(b)  7 sqrt(a) (fast-math path)  8 sin  9 cos  10 pow(a,b) (device libm)
- * 11-18 further primitives of the two arithmetic paths (kr_post.hip::arith_probe_kernel)  19 a after 20 000 additions of b (kr_replay.hpp) */
+ * 11-18 further primitives of the two arithmetic paths (kr_post.hip::arith_probe_kernel)  19 a after 20 000 additions of b (kr_replay.hpp)
+ * 20 1.2345678901234567 / ((a a) b), 21 b / (a a) through the assembled reciprocals of one derivative evaluation (kr_device.hpp::StageRecips) */
 int kr_debug_arith_f64(int op, const double* a, const double* b, double* out, int64_t n);
 
 /* ---- a long-lived host ray array (what Raytracer<T> holds as `rays`) ----------------------------- */

@@ -84,6 +84,42 @@ template <typename T> KR_DEV void energy_guard_set(Lane<T>& s)
 template <typename T> KR_DEV bool energy_flag_needed(const Lane<T>& s, T r_minus_horizon) { return !(r_minus_horizon > T(1e-6)) || s.steps0 < 0; }
 template <typename T> KR_DEV int32_t steps_on_entry(const Lane<T>& s) { return s.steps0 & 0x7fffffff; }
 
+// The five denominators of one derivative evaluation (kerr.h:308-334: rho^2 Delta, sin^2 x that, sin, rho^4, rho^2) are products of one another, so
+// in double precision three reciprocals are taken from the hardware -- of rho^2 Delta, sin and rho^2 -- and the other two are put together from them
+// and polished (lean_recip_from): two quarter-rate instructions less per evaluation on the strict path, whose quotients stay the correctly rounded
+// ones (tests/test_gpu_primitives.py; every ray record of 2e6-ray Euler / RK4 and 1e6-ray RK45 traces unchanged, profiles/r04_ab_experiments.txt).
+// Every quotient is formed against the denominator AS THE REFERENCE ROUNDS IT (rho^2 x rho^2; sin^2 x (rho^2 Delta) or (sin^2 rho^2) Delta).
+// (1 / rho^2 is NOT taken from 1 / (rho^2 Delta): exactly on the horizon, Delta = 0, the reference's thetadot^2 is still finite.)
+template <typename T> struct StageRecips;
+template <> struct StageRecips<double> {
+    double rhosq_delta, sin_theta, sin2_rhosq_delta, rho4, rhosq;
+    double y_rhosq_delta, y_sin, y_sin2_rhosq_delta, y_rho4, y_rhosq;
+    KR_DEV StageRecips(double rhosq_delta_, double sin_theta_, double sin2_rhosq_delta_, double rhosq_, double delta)
+        : rhosq_delta(rhosq_delta_), sin_theta(sin_theta_), sin2_rhosq_delta(sin2_rhosq_delta_), rho4(rhosq_ * rhosq_), rhosq(rhosq_)
+    {
+        y_rhosq_delta = lean_recip(rhosq_delta);
+        y_sin = lean_recip(sin_theta);
+        y_rhosq = lean_recip(rhosq);
+        y_sin2_rhosq_delta = lean_recip_from(sin2_rhosq_delta, y_sin * (y_sin * y_rhosq_delta));      // (in this order: (1 / sin)^2 alone overflows for theta < 1e-154, long before the quotient does)
+        y_rho4 = lean_recip_from(rho4, y_rhosq * y_rhosq);
+    }
+    KR_DEV double over_rhosq_delta(double x) const { return lean_div_y(x, rhosq_delta, y_rhosq_delta); }
+    KR_DEV double over_sin(double x) const { return lean_div_y(x, sin_theta, y_sin); }
+    KR_DEV double over_sin2_rhosq_delta(double x) const { return lean_div_y(x, sin2_rhosq_delta, y_sin2_rhosq_delta); }
+    KR_DEV double over_rho4(double x) const { return lean_div_y(x, rho4, y_rho4); }
+    KR_DEV double over_rhosq(double x) const { return lean_div_y(x, rhosq, y_rhosq); }
+};
+template <> struct StageRecips<float> {
+    float rhosq_delta, sin_theta, sin2_rhosq_delta, rho4, rhosq, y_rhosq;
+    KR_DEV StageRecips(float rhosq_delta_, float sin_theta_, float sin2_rhosq_delta_, float rhosq_, float)
+        : rhosq_delta(rhosq_delta_), sin_theta(sin_theta_), sin2_rhosq_delta(sin2_rhosq_delta_), rho4(rhosq_ * rhosq_), rhosq(rhosq_), y_rhosq(0.0f) {}
+    KR_DEV float over_rhosq_delta(float x) const { return x / rhosq_delta; }
+    KR_DEV float over_sin(float x) const { return x / sin_theta; }
+    KR_DEV float over_sin2_rhosq_delta(float x) const { return x / sin2_rhosq_delta; }
+    KR_DEV float over_rho4(float x) const { return x / rho4; }
+    KR_DEV float over_rhosq(float x) const { return x / rhosq; }
+};
+
 // momentum_from_consts, src/include/kerr.h:300-335
 template <typename T>
 KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a, Lane<T>* keep = nullptr)
@@ -94,15 +130,16 @@ KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int r
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
     const T rhosq_delta = rhosq * delta;
+    const StageRecips<T> y(rhosq_delta, sin_theta, sin2theta * rhosq_delta, rhosq, delta);
     pt = (rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h;
-    pt = dv(pt, rhosq_delta);
+    pt = y.over_rhosq_delta(pt);
 
     pphi = 2 * a * r * sin2theta * k + (rhosq - 2 * r) * h;
-    pphi = dv(pphi, sin2theta * rhosq_delta);
+    pphi = y.over_sin2_rhosq_delta(pphi);
 
-    const T hcs = dv(h * cos_theta, sin_theta);
+    const T hcs = y.over_sin(h * cos_theta);
     T thetadotsq = Q + (k * a * cos_theta + hcs) * (k * a * cos_theta - hcs);
-    thetadotsq = dv(thetadotsq, rhosq * rhosq);
+    thetadotsq = y.over_rho4(thetadotsq);
     const T abs_ptheta = sq(kr_abs(thetadotsq));
     ptheta = abs_ptheta * thetadot_sign;
     if (keep) {      // (see k1_from_last_stage)
@@ -110,7 +147,7 @@ KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int r
     }
 
     T rdotsq = k * pt - h * pphi - rhosq * ptheta * ptheta;
-    rdotsq = dv(rdotsq * delta, rhosq);
+    rdotsq = y.over_rhosq(rdotsq * delta);
     pr = sq(kr_abs(rdotsq)) * rdot_sign;
 }
 
@@ -133,20 +170,14 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y_rhos
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
-    if (RK45_ASSOC) {
-        s.pt = dv((rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h, rhosq * delta);
-        s.pphi = dv(2 * a * r * sin2theta * k + (rhosq - 2 * r) * h, sin2theta * rhosq * delta);
-    } else {
-        const T rhosq_delta = rhosq * delta;
-        s.pt = (rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h;
-        s.pt = dv(s.pt, rhosq_delta);
-        s.pphi = 2 * a * r * sin2theta * k + (rhosq - 2 * r) * h;
-        s.pphi = dv(s.pphi, sin2theta * rhosq_delta);
-    }
+    const T rhosq_delta = rhosq * delta;
+    const StageRecips<T> y(rhosq_delta, sin_theta, RK45_ASSOC ? sin2theta * rhosq * delta : sin2theta * rhosq_delta, rhosq, delta);
+    s.pt = y.over_rhosq_delta((rhosq * (r * r + a * a) + 2 * a * a * r * sin2theta) * k - 2 * a * r * h);
+    s.pphi = y.over_sin2_rhosq_delta(2 * a * r * sin2theta * k + (rhosq - 2 * r) * h);
 
-    const T hcs = dv(h * cos_theta, sin_theta);
+    const T hcs = y.over_sin(h * cos_theta);
     T thetadotsq = s.Q + (k * a * cos_theta + hcs) * (k * a * cos_theta - hcs);
-    thetadotsq = dv(thetadotsq, rhosq * rhosq);
+    thetadotsq = y.over_rho4(thetadotsq);
 
     if (thetadotsq < 0 && s.theta_was_positive) {
         s.thetadot_sign = -s.thetadot_sign;
@@ -158,8 +189,8 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y_rhos
     s.ptheta = sq(kr_abs(thetadotsq)) * s.thetadot_sign;
 
     T rdotsq = k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta;
-    const T y_rhosq = dv_recip(rhosq);          // (the caller's two flag quotients over rho^2 reuse it: step_fixed)
-    rdotsq = dv_y(rdotsq * delta, rhosq, y_rhosq);
+    const T y_rhosq = y.y_rhosq;                // (the caller's two flag quotients over rho^2 reuse it: step_fixed)
+    rdotsq = y.over_rhosq(rdotsq * delta);
     if (rdotsq <= 0 && s.r_was_positive) {
         s.rdot_sign = -s.rdot_sign;
         s.r_was_positive = false;

@@ -499,6 +499,8 @@ __global__ void __launch_bounds__(kBlock) arith_probe_kernel(int op, const doubl
             case 18: r = fifth_root_for_controller(x); break;                        // x^(1/5) of the RK45 step controller
             case 19: r = kr_replay_additions(x, y, 20000); break;                    // 20 000 additions of y to x in closed form (kr_replay.hpp)
             case 17: r = div_by_uniform(x, y, 1.0 / y, true); break;                 // quotient by a launch-uniform divisor (IEEE reciprocal)
+            case 20: { const StageRecips<double> q(y, x, (x * x) * y, 2.0, 1.0); r = q.over_sin2_rhosq_delta(1.2345678901234567); } break;   // x = sin, y = rho^2 Delta: the reciprocals
+            case 21: { const StageRecips<double> q(1.0, 1.0, 1.0, x, 1.0); r = q.over_rho4(y); } break;                                       // x = rho^2:               put together
             case 15: kr_sincos_fast_f64(x, s, c); r = s; break;
             case 16: kr_sincos_fast_f64(x, s, c); r = c; break;
         }

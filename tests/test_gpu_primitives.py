@@ -126,6 +126,24 @@ def test_division_by_a_uniform_constant_is_correctly_rounded(krlib):
         assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), b
 
 
+def test_assembled_reciprocals_give_the_ieee_quotients(krlib):
+    """kr_device.hpp::StageRecips: 1 / (sin^2 rho^2 Delta) and 1 / rho^4 are put together from the reciprocals of sin, rho^2 Delta and rho^2 and polished
+    with one Newton step instead of being taken from the hardware; the quotients formed with them must be the IEEE ones, bit for bit, over the ranges
+    a ray visits (sin theta down to 1e-12: polar-axis rays; rho^2 Delta from 1e-17: next to the horizon)."""
+    rng = np.random.default_rng(20)
+    n = 2_000_000
+    sin = 10.0 ** rng.uniform(-12, 0, n) * rng.choice([-1.0, 1.0], n)
+    b1 = 10.0 ** rng.uniform(-17, 7, n) * rng.choice([-1.0, 1.0], n)
+    got = probe(20, sin, b1)
+    want = 1.2345678901234567 / ((sin * sin) * b1)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    rhosq = 10.0 ** rng.uniform(0, 6.1, n)
+    num = rng.normal(size=n) * 10.0 ** rng.uniform(-20, 20, n)
+    got = probe(21, rhosq, num)
+    want = num / (rhosq * rhosq)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
 def test_fifth_root_of_the_step_controller(krlib):
     """kr_device.hpp::fifth_root_for_controller: within 1.5 ulp of x**0.2 where the DOPRI5 controller can tell (its factor is clamped to
     [0.1, 5], i.e. x in [1.7e-5, 5.3e3]); outside, whatever saturates the clamp the same way; NaN propagates."""
