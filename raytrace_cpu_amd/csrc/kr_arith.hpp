@@ -102,11 +102,11 @@ KR_DEV bool kr_finite(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 
 KR_DEV double kr_sqrt(double x) { return __builtin_sqrt(x); }
 KR_DEV float kr_sqrt(float x) { return __builtin_sqrtf(x); }
-KR_DEV void kr_sincos(double x, double& s, double& c) { kr_sincos_f64(x, s, c); }
+template <bool LONE = false> KR_DEV void kr_sincos(double x, double& s, double& c) { kr_sincos_f64<LONE>(x, s, c); }      // (LONE: kr_sincos.hpp)
 // float: evaluated in double and rounded once -- correctly rounded in all but ~1e-8 of the arguments, which is what glibc's sinf / cosf / powf / tanf
 // (the float instantiation's libm, <= 0.56 ulp) are in all but a few per cent: the float kernels then differ from the reference's float build only
 // where glibc's own float routines are not correctly rounded (the device library's float routines: <= 1-2 ulp).
-KR_DEV void kr_sincos(float x, float& s, float& c)
+template <bool LONE = false> KR_DEV void kr_sincos(float x, float& s, float& c)
 {
     double sd, cd;
     kr_sincos_fast_f64((double) x, sd, cd);

@@ -121,11 +121,11 @@ template <> struct StageRecips<float> {
 };
 
 // momentum_from_consts, src/include/kerr.h:300-335
-template <typename T>
+template <typename T, bool LONE = false>
 KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a, Lane<T>* keep = nullptr)
 {
     T sin_theta, cos_theta;
-    kr_sincos(theta, sin_theta, cos_theta);
+    kr_sincos<LONE>(theta, sin_theta, cos_theta);
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
@@ -161,12 +161,12 @@ KR_DEV void momentum(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_s
 // (raytracer.cpp:177-222, :805-849, :1086-1130, :1370-1398, :1680-1708).  RK45_ASSOC selects the RK45
 // bodies' association of the phidot denominator ((sin2theta*rhosq)*delta, :1375 vs :818).
 // Returns true when the reference would `continue` (theta turning point: sign flipped, nothing moves).
-template <typename T, bool RK45_ASSOC>
+template <typename T, bool RK45_ASSOC, bool LONE = false>
 KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y_rhosq_o = nullptr)
 {
     const T r = s.r, theta = s.theta, k = s.k, h = s.h;
     T sin_theta, cos_theta;
-    kr_sincos(theta, sin_theta, cos_theta);
+    kr_sincos<LONE>(theta, sin_theta, cos_theta);
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
@@ -251,11 +251,11 @@ KR_DEV bool k1_from_last_stage(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y
 namespace kr {
 
 // one derivative evaluation on either path
-template <typename T, bool FAST>
+template <typename T, bool FAST, bool LONE = false>
 KR_DEV void eval(T& pt, T& pr, T& ptheta, T& pphi, const Lane<T>& s, T r, T theta, T a)
 {
     if constexpr (FAST) momentum_fast(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r, theta, a);
-    else momentum_impl<T>(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r, theta, a);
+    else momentum_impl<T, LONE>(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r, theta, a);
 }
 
 // loop condition of the theta-limit overloads (raytracer.cpp:172, :799, :1362-1364) or of the
@@ -335,7 +335,7 @@ KR_DEV bool crossed_equator(T before, T after)
 
 // One iteration of the Euler (raytracer.cpp:172-313) or RK4 (:799-943, :1080-1229) loop body.
 // Returns true when the ray has finished (break, or the loop condition no longer holds).
-template <typename T, bool RK4, bool USE_DEST, bool FAST>
+template <typename T, bool RK4, bool USE_DEST, bool FAST, bool LONE = false>
 KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
 {
     const T a = c.a;
@@ -405,7 +405,7 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         }
     } else {
     T rhosq, sin2theta, y_rhosq;
-    if (k1_with_flips<T, false>(s, a, rhosq, sin2theta, &y_rhosq)) return !(s.steps < c.steplim);   // r, theta unchanged
+    if (k1_with_flips<T, false, LONE>(s, a, rhosq, sin2theta, &y_rhosq)) return !(s.steps < c.steplim);   // r, theta unchanged
     pt1 = s.pt; pr1 = s.pr; ptheta1 = s.ptheta; pphi1 = s.pphi;
 
     // step-size heuristic (:224-243 / :855-871 / :1136-1151)
@@ -469,7 +469,7 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
                     }
                     momentum_fast_sc(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, sn, cs, a);
                 } else {
-                    eval<T, false>(pt, pr, ptheta, pphi, s, r_stage, s.theta + dtheta, a);
+                    eval<T, false, LONE>(pt, pr, ptheta, pphi, s, r_stage, s.theta + dtheta, a);
                 }
             };
             // x1 + 2 x2 as ONE fused multiply-add: 2 x2 is exact, so fma(2, x2, x1) rounds the same sum once -- the reference's bits (:908-912)

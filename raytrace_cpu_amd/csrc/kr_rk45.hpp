@@ -55,7 +55,7 @@ KR_DEV void rk45_seed(Lane<T>& s, const TraceConsts<T>& c)
 // and the momenta left in the record, are accurate to ~1e-11 rather than to the bit).  If k1 does anything but confirm the
 // state (a sign flip, a turning-point flag), everything is put back and the lane returns to full steps.  When both status
 // bits can no longer change, the remaining steps are applied at once.  Returns 1: ray finished, 0: continue, -1: left creep mode.
-template <typename T, bool USE_DEST, bool FAST>
+template <typename T, bool USE_DEST, bool FAST, bool LONE = false>
 KR_DEV int creep_step(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& creep_steps)
 {
     const T a = c.a;
@@ -72,7 +72,7 @@ KR_DEV int creep_step(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
         }
     } else {
         T rhosq, sin2theta;
-        confirmed = !k1_with_flips<T, true>(s, a, rhosq, sin2theta);
+        confirmed = !k1_with_flips<T, true, LONE>(s, a, rhosq, sin2theta);
         if (confirmed) {
             if (s.pt <= 0) s.status |= KR_STATUS_ERGO;
             if ((1 - 2 * s.r / rhosq) * s.pt + (2 * a * s.r * sin2theta / rhosq) * s.pphi < 0) s.status |= KR_STATUS_NEG_ENERGY;
@@ -105,7 +105,7 @@ KR_DEV int creep_step(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
 // the outer step (:1438-1541); here a rejected lane keeps its k1 (s.pt..s.pphi hold k1 until a trial is
 // accepted) and retries on the next iteration, so a rejection never stalls the other 63 lanes.
 // attempts/rejects are per-lane counters.  Returns true when the ray has finished.
-template <typename T, bool USE_DEST, bool FAST>
+template <typename T, bool USE_DEST, bool FAST, bool LONE = false>
 KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, uint32_t& rejects, uint32_t& stationary_steps, uint32_t& creep_steps,
                       int replay_batch)
 {
@@ -116,7 +116,7 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
         if (s.creep_mode) {
             // replay_batch > 1 when every ray of the wave is in creep mode (the tail of a launch): several outer steps per wave iteration
             for (int u = 0; u < replay_batch; ++u) {
-                const int rc = creep_step<T, USE_DEST, FAST>(s, c, attempts, creep_steps);
+                const int rc = creep_step<T, USE_DEST, FAST, LONE>(s, c, attempts, creep_steps);
                 if (rc > 0) return true;
                 if (rc < 0) break;                 // back to full steps, starting with this one
                 if (u + 1 == replay_batch) return false;
@@ -154,9 +154,9 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
         if constexpr (sizeof(T) == 8) {
             // wave-uniform: every lane's data from its last accepted stage is valid (else all recompute -- same bits either way)
             if (__builtin_amdgcn_ballot_w64(!s.fsal_valid) == 0) flipped = k1_from_last_stage<T>(s, a, rhosq, sin2theta, &y_rhosq);
-            else flipped = k1_with_flips<T, true>(s, a, rhosq, sin2theta, &y_rhosq);
+            else flipped = k1_with_flips<T, true, LONE>(s, a, rhosq, sin2theta, &y_rhosq);
         } else {
-            flipped = k1_with_flips<T, true>(s, a, rhosq, sin2theta, &y_rhosq);
+            flipped = k1_with_flips<T, true, LONE>(s, a, rhosq, sin2theta, &y_rhosq);
         }
         if (flipped) return !(s.steps < c.steplim);
         // flags (:1403-1410): same rhosq / sin2theta values as k1's.  The NEG_ENERGY test is the conserved energy k evaluated from tdot and phidot: away
@@ -206,27 +206,27 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T pr2, ptheta2, pr3, ptheta3, pr4, ptheta4, pr5, ptheta5, pr6, ptheta6;
     T sum_t = D::b1 * pt1, sum_phi = D::b1 * pphi1;
 
-    eval<T, FAST>(pt_i, pr2, ptheta2, pphi_i, s, r + h_try * D::a21 * pr1,
+    eval<T, FAST, LONE>(pt_i, pr2, ptheta2, pphi_i, s, r + h_try * D::a21 * pr1,
              theta + h_try * D::a21 * ptheta1, a);
 
-    eval<T, FAST>(pt_i, pr3, ptheta3, pphi_i, s, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
+    eval<T, FAST, LONE>(pt_i, pr3, ptheta3, pphi_i, s, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
              theta + h_try * (D::a31 * ptheta1 + D::a32 * ptheta2), a);
     sum_t = sum_t + D::b3 * pt_i;
     sum_phi = sum_phi + D::b3 * pphi_i;
 
-    eval<T, FAST>(pt_i, pr4, ptheta4, pphi_i, s,
+    eval<T, FAST, LONE>(pt_i, pr4, ptheta4, pphi_i, s,
              r + h_try * (D::a41 * pr1 + D::a42 * pr2 + D::a43 * pr3),
              theta + h_try * (D::a41 * ptheta1 + D::a42 * ptheta2 + D::a43 * ptheta3), a);
     sum_t = sum_t + D::b4 * pt_i;
     sum_phi = sum_phi + D::b4 * pphi_i;
 
-    eval<T, FAST>(pt_i, pr5, ptheta5, pphi_i, s,
+    eval<T, FAST, LONE>(pt_i, pr5, ptheta5, pphi_i, s,
              r + h_try * (D::a51 * pr1 + D::a52 * pr2 + D::a53 * pr3 + D::a54 * pr4),
              theta + h_try * (D::a51 * ptheta1 + D::a52 * ptheta2 + D::a53 * ptheta3 + D::a54 * ptheta4), a);
     sum_t = sum_t + D::b5 * pt_i;
     sum_phi = sum_phi + D::b5 * pphi_i;
 
-    eval<T, FAST>(pt_i, pr6, ptheta6, pphi_i, s,
+    eval<T, FAST, LONE>(pt_i, pr6, ptheta6, pphi_i, s,
              r + h_try * (D::a61 * pr1 + D::a62 * pr2 + D::a63 * pr3 + D::a64 * pr4 + D::a65 * pr5),
              theta + h_try * (D::a61 * ptheta1 + D::a62 * ptheta2 + D::a63 * ptheta3 + D::a64 * ptheta4 + D::a65 * ptheta5), a);
     sum_t = sum_t + D::b6 * pt_i;
@@ -245,9 +245,9 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T pt7, pr7, ptheta7, pphi7;
     Lane<T> last;                   // (only its f_* members are written, and only on the strict double path)
     if constexpr (!FAST && sizeof(T) == 8)
-        momentum_impl<T>(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a, &last);
+        momentum_impl<T, LONE>(pt7, pr7, ptheta7, pphi7, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_new, theta_new, a, &last);
     else
-        eval<T, FAST>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
+        eval<T, FAST, LONE>(pt7, pr7, ptheta7, pphi7, s, r_new, theta_new, a);
 
     // error norm over (r, theta) and the step controller (:1508-1519)
     const T err_r = h_try * (D::e1 * pr1 + D::e3 * pr3 + D::e4 * pr4 + D::e5 * pr5 + D::e6 * pr6 + D::e7 * pr7);

@@ -143,11 +143,17 @@ KR_SC_FN void kr_sincos_cr_core_f64(double r, double y, double& sr, double& cr)
 // the ray sources, the stop tests).  A pure function of x, so a ray gets the same bits in whichever kernel / wave it is traced.
 // (The shorter fdlibm minimax kernels this replaced -- max 0.84 ulp, equal to glibc on 96.5 % of arguments against 99.7-99.99 % -- are in the history
 // of this file; profiles/r02_ab_experiments.txt has their timings.)
+// LONE: the caller is a wave that owns its SIMD (the strict side launch: polar-axis rays, whose angles are small for most of their tens of thousands
+// of steps).  Nothing covers such a wave's branch bubbles, so the small-angle path is laid out as the fall-through and the general one out of line:
+// side launches 1.6-1.8 % shorter; the same layout in the ordinary strict kernels, where the general path is the usual one, costs them 3-5 %
+// (profiles/r04_ab_experiments.txt).  Same values either way.
+template <bool LONE = false>
 KR_SC_FN void kr_sincos_f64(double x, double& s, double& c)
 {
     const bool small = __builtin_fabs(x) < KR_SMALL_ANGLE_LIMIT;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (__builtin_amdgcn_ballot_w64(!small) == 0) {      // every active lane: the usual case on a wave of polar-axis rays
+    const bool all_small = __builtin_amdgcn_ballot_w64(!small) == 0;      // every active lane: the usual case on a wave of polar-axis rays
+    if (LONE ? __builtin_expect(all_small, 1) : all_small) {
         kr_sincos_small_f64(x, s, c);
         return;
     }

@@ -285,9 +285,9 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
 #endif
         if (have) {
             bool fin;
-            if (METHOD == KR_EULER) fin = step_fixed<T, false, USE_DEST, FAST>(s, c);
-            else if (METHOD == KR_RK4) fin = step_fixed<T, true, USE_DEST, FAST>(s, c);
-            else fin = step_rk45<T, USE_DEST, FAST>(s, c, my_attempts, my_rejects, my_stationary, my_creep, replay_batch);
+            if (METHOD == KR_EULER) fin = step_fixed<T, false, USE_DEST, FAST, HOG>(s, c);
+            else if (METHOD == KR_RK4) fin = step_fixed<T, true, USE_DEST, FAST, HOG>(s, c);
+            else fin = step_rk45<T, USE_DEST, FAST, HOG>(s, c, my_attempts, my_rejects, my_stationary, my_creep, replay_batch);
             if (fin) {
                 have = false;
                 pend = true;
