@@ -121,11 +121,14 @@ template <> struct StageRecips<float> {
 };
 
 // momentum_from_consts, src/include/kerr.h:300-335
-template <typename T, bool LONE = false>
+// SMALL_ANGLE (double): the caller vouches for |theta| < KR_SMALL_ANGLE_LIMIT (step_fixed's side-launch stages): kr_sincos_f64's small-angle branch
+// without its test.
+template <typename T, bool LONE = false, bool SMALL_ANGLE = false>
 KR_DEV void momentum_impl(T& pt, T& pr, T& ptheta, T& pphi, T k, T h, T Q, int rdot_sign, int thetadot_sign, T r, T theta, T a, Lane<T>* keep = nullptr)
 {
     T sin_theta, cos_theta;
-    kr_sincos<LONE>(theta, sin_theta, cos_theta);
+    if constexpr (SMALL_ANGLE && sizeof(T) == 8) kr_sincos_small_f64(theta, sin_theta, cos_theta);
+    else kr_sincos<LONE>(theta, sin_theta, cos_theta);
     const T sin2theta = sin_theta * sin_theta;
     const T rhosq = r * r + (a * cos_theta) * (a * cos_theta);
     const T delta = r * r - 2 * r + a * a;
@@ -468,6 +471,10 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
                         kr_sincos_fast_f64(s.theta + dtheta, sn, cs);
                     }
                     momentum_fast_sc(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, sn, cs, a);
+                } else if constexpr (kNear) {
+                    const T theta_stage = s.theta + dtheta;
+                    within = within && (kr_abs(theta_stage) < T(KR_SMALL_ANGLE_LIMIT));
+                    momentum_impl<T, LONE, true>(pt, pr, ptheta, pphi, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, theta_stage, a);
                 } else {
                     eval<T, false, LONE>(pt, pr, ptheta, pphi, s, r_stage, s.theta + dtheta, a);
                 }
@@ -491,6 +498,16 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         };
         if constexpr (FAST) {
             if (!stages(std::true_type{})) stages(std::false_type{});
+        } else if constexpr (LONE && sizeof(T) == 8) {
+            // Strict path on a wave that owns its SIMD (polar-axis rays: the critical path of the pass).  Nothing covers such a wave's branch bubbles,
+            // and kr_sincos_f64 costs two compare-dependent branches per stage to pick its small-angle formula.  While the base angle is small on
+            // every lane the three stages take that formula unasked, record whether their angles were small too, and are redone with the full
+            // routine if not: the same values, one branch instead of six.
+            bool done = false;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(kr_abs(s.theta) < T(KR_SMALL_ANGLE_LIMIT))) == 0, 1)) done = stages(std::true_type{});
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!done) != 0, 0)) {
+                if (!done) stages(std::false_type{});
+            }
         } else {
             stages(std::false_type{});
         }

@@ -202,35 +202,55 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
 
     // stages 2..6; the b- and e-weighted sums are accumulated in stage order, which is the reference's
     // left-to-right order (:1493-1496, :1508-1509), so only (pr_i, ptheta_i) stay live across stages
-    T pt_i, pphi_i;
     T pr2, ptheta2, pr3, ptheta3, pr4, ptheta4, pr5, ptheta5, pr6, ptheta6;
-    T sum_t = D::b1 * pt1, sum_phi = D::b1 * pphi1;
+    T sum_t, sum_phi;
+    // (small: the side launches' optimistic form of the five stages, as in step_fixed -- the small-angle sine / cosine unasked while the base angle
+    // is small on every lane, the stages redone with the full routine if one of their angles was not: two branches instead of ten)
+    auto stages = [&](auto small) -> bool {
+        constexpr bool kSmall = decltype(small)::value;
+        bool within = true;
+        T pt_i, pphi_i;
+        auto stage = [&](T& pr_o, T& ptheta_o, T r_stage, T theta_stage) {
+            if constexpr (kSmall) {
+                within = within && (kr_abs(theta_stage) < T(KR_SMALL_ANGLE_LIMIT));
+                momentum_impl<T, LONE, true>(pt_i, pr_o, ptheta_o, pphi_i, s.k, s.h, s.Q, s.rdot_sign, s.thetadot_sign, r_stage, theta_stage, a);
+            } else {
+                eval<T, FAST, LONE>(pt_i, pr_o, ptheta_o, pphi_i, s, r_stage, theta_stage, a);
+            }
+        };
+        sum_t = D::b1 * pt1;
+        sum_phi = D::b1 * pphi1;
 
-    eval<T, FAST, LONE>(pt_i, pr2, ptheta2, pphi_i, s, r + h_try * D::a21 * pr1,
-             theta + h_try * D::a21 * ptheta1, a);
+        stage(pr2, ptheta2, r + h_try * D::a21 * pr1, theta + h_try * D::a21 * ptheta1);
 
-    eval<T, FAST, LONE>(pt_i, pr3, ptheta3, pphi_i, s, r + h_try * (D::a31 * pr1 + D::a32 * pr2),
-             theta + h_try * (D::a31 * ptheta1 + D::a32 * ptheta2), a);
-    sum_t = sum_t + D::b3 * pt_i;
-    sum_phi = sum_phi + D::b3 * pphi_i;
+        stage(pr3, ptheta3, r + h_try * (D::a31 * pr1 + D::a32 * pr2), theta + h_try * (D::a31 * ptheta1 + D::a32 * ptheta2));
+        sum_t = sum_t + D::b3 * pt_i;
+        sum_phi = sum_phi + D::b3 * pphi_i;
 
-    eval<T, FAST, LONE>(pt_i, pr4, ptheta4, pphi_i, s,
-             r + h_try * (D::a41 * pr1 + D::a42 * pr2 + D::a43 * pr3),
-             theta + h_try * (D::a41 * ptheta1 + D::a42 * ptheta2 + D::a43 * ptheta3), a);
-    sum_t = sum_t + D::b4 * pt_i;
-    sum_phi = sum_phi + D::b4 * pphi_i;
+        stage(pr4, ptheta4, r + h_try * (D::a41 * pr1 + D::a42 * pr2 + D::a43 * pr3), theta + h_try * (D::a41 * ptheta1 + D::a42 * ptheta2 + D::a43 * ptheta3));
+        sum_t = sum_t + D::b4 * pt_i;
+        sum_phi = sum_phi + D::b4 * pphi_i;
 
-    eval<T, FAST, LONE>(pt_i, pr5, ptheta5, pphi_i, s,
-             r + h_try * (D::a51 * pr1 + D::a52 * pr2 + D::a53 * pr3 + D::a54 * pr4),
-             theta + h_try * (D::a51 * ptheta1 + D::a52 * ptheta2 + D::a53 * ptheta3 + D::a54 * ptheta4), a);
-    sum_t = sum_t + D::b5 * pt_i;
-    sum_phi = sum_phi + D::b5 * pphi_i;
+        stage(pr5, ptheta5, r + h_try * (D::a51 * pr1 + D::a52 * pr2 + D::a53 * pr3 + D::a54 * pr4),
+              theta + h_try * (D::a51 * ptheta1 + D::a52 * ptheta2 + D::a53 * ptheta3 + D::a54 * ptheta4));
+        sum_t = sum_t + D::b5 * pt_i;
+        sum_phi = sum_phi + D::b5 * pphi_i;
 
-    eval<T, FAST, LONE>(pt_i, pr6, ptheta6, pphi_i, s,
-             r + h_try * (D::a61 * pr1 + D::a62 * pr2 + D::a63 * pr3 + D::a64 * pr4 + D::a65 * pr5),
-             theta + h_try * (D::a61 * ptheta1 + D::a62 * ptheta2 + D::a63 * ptheta3 + D::a64 * ptheta4 + D::a65 * ptheta5), a);
-    sum_t = sum_t + D::b6 * pt_i;
-    sum_phi = sum_phi + D::b6 * pphi_i;
+        stage(pr6, ptheta6, r + h_try * (D::a61 * pr1 + D::a62 * pr2 + D::a63 * pr3 + D::a64 * pr4 + D::a65 * pr5),
+              theta + h_try * (D::a61 * ptheta1 + D::a62 * ptheta2 + D::a63 * ptheta3 + D::a64 * ptheta4 + D::a65 * ptheta5));
+        sum_t = sum_t + D::b6 * pt_i;
+        sum_phi = sum_phi + D::b6 * pphi_i;
+        return within;
+    };
+    if constexpr (LONE && !FAST && sizeof(T) == 8) {
+        bool done = false;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(kr_abs(theta) < T(KR_SMALL_ANGLE_LIMIT))) == 0, 1)) done = stages(std::true_type{});
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!done) != 0, 0)) {
+            if (!done) stages(std::false_type{});
+        }
+    } else {
+        stages(std::false_type{});
+    }
 
     // 5th-order solution (:1493-1499); the polar reflection mutates thetadot_sign even if the trial is rejected
     const T inc_r = h_try * (D::b1 * pr1 + D::b3 * pr3 + D::b4 * pr4 + D::b5 * pr5 + D::b6 * pr6);

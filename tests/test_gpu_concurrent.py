@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import bench
+import parity
 from raytrace_cpu_amd import api, capi
 
 pytestmark = pytest.mark.gpu
@@ -37,8 +38,7 @@ class DeviceRays:
         self.lib.kr_free(self.d)
 
 
-def same_bits(a, b):
-    return all((a[f].view(np.int64) == b[f].view(np.int64)).all() if a[f].dtype.kind == "f" else (a[f] == b[f]).all() for f in a.dtype.names)
+same_bits = parity.same_records      # (bit for bit; a NaN equals a NaN)
 
 
 @pytest.mark.parametrize("flags", [pytest.param(capi.FLAG_HYBRID, id="hybrid"), pytest.param(0, id="strict-split")])

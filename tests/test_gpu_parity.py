@@ -569,9 +569,7 @@ def test_return_radiation_vs_oracle(krlib):
 
 
 # ---- hybrid mode is exactly "strict for the flagged rays, fast for the others" ------------------------------------
-def _same_bits(a, b):
-    return all(np.array_equal(a[f].view(np.uint8 if a[f].dtype.itemsize == 1 else f"u{a[f].dtype.itemsize}"),
-                              b[f].view(np.uint8 if b[f].dtype.itemsize == 1 else f"u{b[f].dtype.itemsize}")) for f in a.dtype.names)
+_same_bits = parity.same_records      # (bit for bit; a NaN equals a NaN)
 
 
 @pytest.mark.parametrize("method", [capi.RK4, capi.RK45])
