@@ -1,9 +1,11 @@
 #!/bin/bash
 # GPU box: round-4 record run of the final tree -- every bench workload (the first two with their cpu_baseline leg: pipeline_bins_check /
 # pipeline_planes_check of the TIMED pipeline), the RK45 sweep, the RCCL path on one rank, the app wall times, then scripts/profile_all.sh (kernel
-# trace + PMC passes of all five workloads: the counter record of the round).  usage: KR_TREE_COMMIT=<sha> scripts/gpu_record_run_r04.sh
+# trace + PMC passes of all five workloads: the counter record of the round).  usage: KR_TREE_COMMIT=<sha> scripts/gpu_record_run_r04.sh [bench|profile <workload ...>]
+# (one gpurun call is limited to 20 minutes: "bench" is the first half, "profile rk4 rk45 euler" and "profile imageplane return_radiation" the second)
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/record_r04; mkdir -p $O
+if [ "$1" = "profile" ]; then shift; scripts/profile_all.sh r04 "$@" > $O/profile_$1.log 2>&1; tail -3 $O/profile_$1.log; exit 0; fi
 timeout -k 10 900 python bench.py > $O/bench_n1_emissivity.json 2> $O/err_emis.txt || tail -3 $O/err_emis.txt
 timeout -k 10 400 python bench.py --workload imageplane > $O/bench_n1_imageplane.json 2> $O/err_ip.txt || tail -3 $O/err_ip.txt
 timeout -k 10 300 python bench.py --workload return_radiation --no-cpu-baseline > $O/bench_n1_return_radiation.json 2> $O/err_rr.txt || tail -3 $O/err_rr.txt
@@ -29,4 +31,4 @@ import json
 d = json.load(open("gpurun_out/record_r04/rk45_tol_sweep_strict.json"))
 print("sweep strict", [(r["h"], r["tol"], round(r["kernel_ms"])) for r in d["runs"] if r["integrator"] == "rk45"][::4], {k: v for k, v in d["concurrent"].items() if k != "per_point_span_ms"})
 PY
-scripts/profile_all.sh r04 > $O/profile.log 2>&1; tail -3 $O/profile.log
+if [ "$1" != "bench" ]; then scripts/profile_all.sh r04 > $O/profile.log 2>&1; tail -3 $O/profile.log; fi
