@@ -97,6 +97,12 @@ json.dump(res, open(out, "w"), indent=1)
 # HBM traffic of the trace kernels per pass (what bench.py's roofline.traffic_from_profile quotes)
 tfile = os.path.join(os.path.dirname(src), "trace_kernel_hbm_traffic.json")
 t = json.load(open(tfile)) if os.path.exists(tfile) else {}
+# (a round's workloads may be profiled in several gpurun calls, each on a fresh box: entries of the committed file that belong to the same tree are kept)
+committed = os.path.join(root, "profiles", "trace_kernel_hbm_traffic.json")
+if os.path.exists(committed):
+    old = json.load(open(committed))
+    if commit in str(old.get("_source", "")):
+        t = {**old, **t}
 rd = sum(k["counters_per_launch"].get("FETCH_SIZE", 0) * k.get("launches_per_pass", 1) for k in res["kernels"].values()) * 1024
 wr = sum(k["counters_per_launch"].get("WRITE_SIZE", 0) * k.get("launches_per_pass", 1) for k in res["kernels"].values()) * 1024
 key = {"rk4": "emissivity_rk4", "rk45": "emissivity_rk45", "euler": "emissivity_euler", "imageplane": "imageplane_rk4", "return_radiation": "return_radiation_euler"}[wl]
