@@ -194,7 +194,13 @@ KR_DEV bool k1_with_flips(Lane<T>& s, T a, T& rhosq_o, T& sin2theta_o, T* y_rhos
     T rdotsq = k * s.pt - h * s.pphi - rhosq * s.ptheta * s.ptheta;
     const T y_rhosq = y.y_rhosq;                // (the caller's two flag quotients over rho^2 reuse it: step_fixed)
     rdotsq = y.over_rhosq(rdotsq * delta);
-    if (rdotsq <= 0 && s.r_was_positive) {
+    if constexpr (LONE) {
+        // (the same bookkeeping as selects: the if / else costs a wave that owns its SIMD a taken branch around a one-instruction else arm on every step)
+        const bool flip = rdotsq <= 0 && s.r_was_positive;
+        s.rdot_sign = flip ? -s.rdot_sign : s.rdot_sign;
+        s.rdot_flips += flip ? 1 : 0;
+        s.r_was_positive = !flip && (s.r_was_positive || rdotsq > 0);
+    } else if (rdotsq <= 0 && s.r_was_positive) {
         s.rdot_sign = -s.rdot_sign;
         s.r_was_positive = false;
         s.rdot_flips++;
@@ -321,11 +327,15 @@ KR_DEV T dest_step_limit(const TraceConsts<T>& c, T r, T theta, T ptheta)
 }
 
 // polar reflection, raytracer.cpp:282-283 / :914-915 / :1498-1499
-template <typename T>
+template <typename T, bool LONE = false>
 KR_DEV void reflect_poles(T& theta, T& phi, int32_t& thetadot_sign)
 {
     // a pole crossing is rare: one wave-uniform test, and the per-lane selects only in a wave that has one
-    if (__builtin_amdgcn_ballot_w64(theta < T(0) || theta > T(kPi)) == 0) return;
+    if constexpr (LONE) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(theta < T(0) || theta > T(kPi)) == 0, true)) return;     // (the usual path falls through)
+    } else {
+        if (__builtin_amdgcn_ballot_w64(theta < T(0) || theta > T(kPi)) == 0) return;
+    }
     if (theta < T(0)) { theta = -theta; thetadot_sign = -thetadot_sign; phi += T(kPi); }
     if (theta > T(kPi)) { theta = T(2) * T(kPi) - theta; thetadot_sign = -thetadot_sign; phi += T(kPi); }
 }
@@ -437,7 +447,8 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
     // bounded (energy_guard_set) so that with r - r_horizon > 1e-6 (Delta > 1e-9 for every a < 0.99999), k > 0 and |h| <= 1e6 k the sum cannot come out
     // negative, in the reference or here.  The flag is therefore only evaluated -- with the reference's operations -- by waves in which some ray is that
     // close to the horizon or carries the mark.
-    if (sizeof(T) == 4 || __builtin_amdgcn_ballot_w64(energy_flag_needed(s, s.r - c.horizon)) != 0) {
+    const bool flag_somewhere = __builtin_amdgcn_ballot_w64(energy_flag_needed(s, s.r - c.horizon)) != 0;
+    if (sizeof(T) == 4 || (LONE ? __builtin_expect(flag_somewhere, false) : flag_somewhere)) {       // (LONE: the evaluation out of line, the usual path falls through)
         if ((1 - dv_y(2 * s.r, rhosq, y_rhosq)) * pt1 + dv_y(2 * a * s.r * sin2theta, rhosq, y_rhosq) * pphi1 < 0) s.status |= KR_STATUS_NEG_ENERGY;
     }
     }
@@ -526,7 +537,7 @@ KR_DEV bool step_fixed(Lane<T>& s, const TraceConsts<T>& c)
         }
     }
     if (crossed_equator(theta_prev, s.theta)) ++s.eq_cross;
-    reflect_poles(s.theta, s.phi, s.thetadot_sign);
+    reflect_poles<T, LONE>(s.theta, s.phi, s.thetadot_sign);
 
     if (s.r <= c.horizon) { s.status |= KR_STATUS_HORIZON; return true; }
     if (USE_DEST) {

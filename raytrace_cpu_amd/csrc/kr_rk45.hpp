@@ -260,7 +260,7 @@ KR_DEV bool step_rk45(Lane<T>& s, const TraceConsts<T>& c, uint32_t& attempts, u
     T t_new = s.t + h_try * sum_t;
     T phi_new = s.phi + h_try * sum_phi;
     const bool inside_poles = !(theta_new < T(0)) && !(theta_new > T(kPi));
-    reflect_poles(theta_new, phi_new, s.thetadot_sign);
+    reflect_poles<T, LONE>(theta_new, phi_new, s.thetadot_sign);
 
     T pt7, pr7, ptheta7, pphi7;
     Lane<T> last;                   // (only its f_* members are written, and only on the strict double path)
