@@ -322,6 +322,19 @@ KR_DEV void trace_body(typename RayOf<T>::type* __restrict__ rays, long long n, 
     }
 }
 
+// A wave that owns its SIMD has 512 vector registers to itself and the same ~100 scalar ones as any other wave: in the side launch's kernels the launch
+// constants live in vector registers (the empty asm makes them opaque to the compiler's uniformity analysis) instead of being spilled to lanes and
+// read back in the step loop, where such a wave pays four cycles for every instruction of any kind.  Euler and RK45 side launches -2 ... -3 %; the RK4
+// kernel's allocation comes out 1 % slower with it and stays as it was (profiles/r04_ab_experiments.txt).
+template <typename T> KR_DEV void consts_into_vector_registers(TraceConsts<T>& c)
+{
+    if constexpr (sizeof(T) == 8) {
+        auto hold = [](T& x) { asm("" : "+v"(x)); };
+        hold(c.a); hold(c.horizon); hold(c.rlim); hold(c.precision); hold(c.theta_precision); hold(c.max_tstep); hold(c.tol);
+        hold(c.inv_precision); hold(c.inv_theta_precision); hold(c.tstep_rlim_eff); hold(c.phistep_eff); hold(c.theta_lo); hold(c.theta_hi);
+    }
+}
+
 template <typename T, int METHOD, bool USE_DEST, bool FAST, bool HOG, int REFILL_MIN>
 __global__ void __attribute__((amdgpu_flat_work_group_size(kTraceBlock, kTraceBlock))) KR_WAVES_ATTR
 trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConsts<T> c, unsigned long long* __restrict__ counters,
@@ -330,6 +343,7 @@ trace_kernel(typename RayOf<T>::type* __restrict__ rays, long long n, TraceConst
     if (HOG) asm volatile("; claim the whole register file" ::: "v255", "a255");
     int has_prio = 0;
     if constexpr (HOG) {
+        if constexpr (METHOD != KR_RK4) consts_into_vector_registers(c);
         trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(rays, n, c, counters, list, n_ptr, n_mode, mask, mask_want, has_prio, (long long) blockIdx.x * 64,
                                                                (unsigned long long) gridDim.x * 64);
     } else {
@@ -356,8 +370,15 @@ trace_multi_kernel(const TraceDesc<T>* __restrict__ descs, int n_desc, const int
     if constexpr (HOG) {
         // (HOG batches map workgroup -> trace by modulo: workgroup b is the (b / n_desc)-th of its trace's gridDim.x / n_desc workgroups)
         const long long g = (long long) (blockIdx.x / (unsigned) n_desc);
-        trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(d->rays, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio, g * 64,
-                                                               (unsigned long long) (gridDim.x / (unsigned) n_desc) * 64);
+        if constexpr (METHOD != KR_RK4) {
+            TraceConsts<T> c = d->c;
+            consts_into_vector_registers(c);
+            trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(d->rays, d->n, c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio, g * 64,
+                                                                   (unsigned long long) (gridDim.x / (unsigned) n_desc) * 64);
+        } else {
+            trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(d->rays, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio, g * 64,
+                                                                   (unsigned long long) (gridDim.x / (unsigned) n_desc) * 64);
+        }
     } else {
         trace_body<T, METHOD, USE_DEST, FAST, HOG, REFILL_MIN>(d->rays, d->n, d->c, d->counters, d->list, d->n_ptr, d->n_mode, d->mask, d->mask_want, has_prio);
     }
