@@ -572,7 +572,7 @@ def test_return_radiation_vs_oracle(krlib):
 _same_bits = parity.same_records      # (bit for bit; a NaN equals a NaN)
 
 
-@pytest.mark.parametrize("method", [capi.RK4, capi.RK45])
+@pytest.mark.parametrize("method", [capi.EULER, capi.RK4, capi.RK45])
 def test_hybrid_is_the_union_of_strict_and_fast(krlib, method):
     g = np.load(gc.golden_path("ps_h10"))
     init = g["init"]
